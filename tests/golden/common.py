@@ -1,0 +1,86 @@
+"""Seeded weights / inputs shared by the fixture generator and the tests that replay the
+fixtures.  Test infrastructure: imports the oracle, never imported by the product."""
+import numpy as np
+import torch
+
+from oracle import multimae_oracle as O
+
+TINY_GRAD_NAMES = [
+    "global_tokens",
+    "input_adapters.depth.proj.weight",
+    "input_adapters.rgb.proj.bias",
+    "encoder.0.attn.qkv.weight",
+    "encoder.1.mlp.fc2.bias",
+    "encoder.1.norm2.weight",
+    "output_adapters.rgb.mask_token",
+    "output_adapters.rgb.task_embeddings.depth",
+    "output_adapters.depth.out_proj.bias",
+    "output_adapters.norm_rgb.decoder.kv.weight",
+    "output_adapters.depth.proj_context.weight",
+]
+
+
+def _perturb(sd, seed, scale=0.05):
+    """Zero/one-initialised tensors (biases, LayerNorm, mask_token) get noise so every
+    term of the arithmetic is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in sd.items():
+        if k.endswith("pos_emb"):
+            out[k] = v.clone()
+        elif v.ndim <= 1 or "mask_token" in k or "task_embeddings" in k or "global_tokens" in k:
+            out[k] = v + scale * torch.randn(v.shape, generator=g)
+        else:
+            out[k] = v.clone()
+    return out
+
+
+def perturbed_state(cfg, seed):
+    return _perturb(O.init_state(cfg, seed), seed + 1000)
+
+
+def perturbed_block_state(prefix, dim, hidden, seed):
+    cfg = O.make_cfg({"rgb": 3}, {}, dim=dim, depth=1, heads=4, mlp_ratio=hidden / dim, image=16)
+    sd = O.init_state(cfg, seed)
+    sd = {k.replace("encoder.0", prefix): v for k, v in sd.items() if k.startswith("encoder.0.")}
+    return _perturb(sd, seed + 1000)
+
+
+def perturbed_xattn_state(prefix, dim, seed):
+    cfg = O.make_cfg({"rgb": 3}, {"rgb": (3, "rgb")}, dim=64, depth=0, dec_dim=dim, dec_depth=0, dec_heads=4, image=16)
+    sd = O.init_state(cfg, seed)
+    pre = "output_adapters.rgb.decoder."
+    sd = {prefix + "." + k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    return _perturb(sd, seed + 1000)
+
+
+def seeded_inputs(cfg, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    S = cfg["image"]
+    x = {}
+    for d, C in cfg["in_domains"].items():
+        if d == "rgb":
+            x[d] = torch.randn(B, C, S, S, generator=g)
+        else:
+            x[d] = torch.rand(B, C, S, S, generator=g)
+    return x
+
+
+def mask_keys(p, noises, noise_all, k):
+    """The fp32 sort keys of the second argsort (preliminary mask + global noise)."""
+    kt = O.samples_per_task(p, k)
+    pre = [torch.where(torch.argsort(n, dim=1, stable=True) < kt[:, i:i + 1], 0, 1) for i, n in enumerate(noises)]
+    return torch.cat(pre, 1) + noise_all
+
+
+def assert_tie_free(p, noises, noise_all, k):
+    for n in noises:
+        for row in n:
+            assert row.unique().numel() == row.numel(), "tie in per-task noise"
+    for row in mask_keys(p, noises, noise_all, k):
+        assert row.unique().numel() == row.numel(), "tie in global sort key"
+
+
+def load(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), name))

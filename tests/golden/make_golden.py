@@ -1,0 +1,274 @@
+"""Generate the golden fixtures in this directory by running the REFERENCE implementation.
+
+Run in the build container only (needs /root/reference, which never travels):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Every fixture is data: seeds / inputs and the outputs the reference's ``multimae``
+package produced for them.  Weights and image inputs are regenerated from seeds by
+``oracle.multimae_oracle`` helpers (``perturbed_state``/``seeded_inputs``) and loaded
+into the reference modules with ``load_state_dict(strict=True)``, which also pins the
+state_dict key names and shapes.
+"""
+import hashlib
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+warnings.filterwarnings("ignore")
+
+from torch.distributions.dirichlet import Dirichlet  # noqa: E402
+
+import multimae as ref  # noqa: E402  (the reference package)
+from multimae.multimae_utils import Block as RefBlock, CrossAttention as RefXAttn, build_2d_sincos_posemb  # noqa: E402
+from oracle import multimae_oracle as O  # noqa: E402
+from tests.golden import common as G  # noqa: E402
+
+
+def build_ref_model(cfg):
+    n_img = cfg["image"]
+    ia = {d: ref.PatchedInputAdapter(num_channels=C, stride_level=1, patch_size_full=cfg["patch"],
+                                     image_size=n_img) for d, C in cfg["in_domains"].items()}
+    oa = {name: ref.SpatialOutputAdapter(num_channels=C, stride_level=1, patch_size_full=cfg["patch"],
+                                         dim_tokens=cfg["dec_dim"], depth=cfg["dec_depth"],
+                                         num_heads=cfg["dec_heads"], use_task_queries=True, task=task,
+                                         context_tasks=list(cfg["in_domains"]), use_xattn=True,
+                                         image_size=n_img)
+          for name, (C, task) in cfg["out_domains"].items()}
+    return ref.MultiMAE(ia, oa, num_global_tokens=cfg["num_global"], dim_tokens=cfg["dim"],
+                        depth=cfg["depth"], num_heads=cfg["heads"])
+
+
+class _Tokens(dict):
+    pass
+
+
+def replay_mask_rng(seed, B, sizes, alphas, uniform):
+    """Draw, in the reference's call order (multimae/multimae.py:211-237), the values its
+    generate_random_masks will consume after torch.manual_seed(seed)."""
+    torch.manual_seed(seed)
+    T = len(sizes)
+    al = [alphas] * T if isinstance(alphas, float) else alphas
+    if uniform:
+        dummy = ref.MultiMAE.sample_alphas(None, B, T, alphas=al)
+        p = Dirichlet(dummy).sample()
+    else:
+        p = Dirichlet(torch.Tensor(al)).sample((B,))
+    noises = [torch.rand(B, n) for n in sizes]
+    noise_all = torch.rand(B, sum(sizes))
+    return p, noises, noise_all
+
+
+def gen_masks():
+    out = {}
+    model = build_ref_model(O.tiny_cfg())
+    case = 0
+    for T in (2, 3):
+        for k in (98, 196):
+            for seed in range(4):
+                B, sizes = 8, [196] * T
+                p, noises, noise_all = replay_mask_rng(seed, B, sizes, 1.0, False)
+                toks = {f"t{i}": torch.zeros(B, n, 1) for i, n in enumerate(sizes)}
+                torch.manual_seed(seed)
+                masks, ids_keep, ids_restore = model.generate_random_masks(toks, k, alphas=1.0)
+                key = torch.cat([m for m in masks.values()], 1)  # final masks; tie check on real keys below
+                G.assert_tie_free(p, noises, noise_all, k)
+                pre = f"c{case}_"
+                out[pre + "k"] = np.int64(k)
+                out[pre + "p"] = p.numpy()
+                for i, nz in enumerate(noises):
+                    out[pre + f"noise{i}"] = nz.numpy()
+                out[pre + "noise_all"] = noise_all.numpy()
+                out[pre + "ids_keep"] = ids_keep.numpy().astype(np.int16)
+                out[pre + "ids_restore"] = ids_restore.numpy().astype(np.int16)
+                out[pre + "mask"] = key.numpy().astype(np.uint8)
+                case += 1
+    # sample_tasks_uniformly (alphas rows with eps entries), T=2 and T=3
+    for T in (2, 3):
+        B, sizes, k, seed = 8, [196] * T, 98, 11 + T
+        p, noises, noise_all = replay_mask_rng(seed, B, sizes, 1.0, True)
+        toks = {f"t{i}": torch.zeros(B, n, 1) for i, n in enumerate(sizes)}
+        torch.manual_seed(seed)
+        masks, ids_keep, ids_restore = model.generate_random_masks(toks, k, alphas=1.0, sample_tasks_uniformly=True)
+        G.assert_tie_free(p, noises, noise_all, k)
+        pre = f"c{case}_"
+        out[pre + "k"] = np.int64(k)
+        out[pre + "p"] = p.numpy()
+        for i, nz in enumerate(noises):
+            out[pre + f"noise{i}"] = nz.numpy()
+        out[pre + "noise_all"] = noise_all.numpy()
+        out[pre + "ids_keep"] = ids_keep.numpy().astype(np.int16)
+        out[pre + "ids_restore"] = ids_restore.numpy().astype(np.int16)
+        out[pre + "mask"] = torch.cat(list(masks.values()), 1).numpy().astype(np.uint8)
+        case += 1
+    out["n_cases"] = np.int64(case)
+    # how often does sum(round(p*k)) differ from k in these cases (must be exercised)
+    np.savez_compressed(os.path.join(HERE, "masks.npz"), **out)
+    print("masks:", case, "cases")
+
+
+def gen_posemb():
+    out = {}
+    for (h, w, d) in [(14, 14, 768), (14, 14, 256), (3, 5, 8), (24, 24, 1024)]:
+        t = build_2d_sincos_posemb(h, w, d).contiguous()
+        tag = f"{h}x{w}x{d}"
+        out[tag + "_sha256"] = np.frombuffer(hashlib.sha256(t.numpy().tobytes()).digest(), dtype=np.uint8)
+        flat = t.flatten()
+        idx = torch.linspace(0, flat.numel() - 1, 64).long()
+        out[tag + "_probe_idx"] = idx.numpy()
+        out[tag + "_probe_val"] = flat[idx].numpy()
+        if flat.numel() <= 4096:
+            out[tag + "_full"] = t.numpy()
+    np.savez_compressed(os.path.join(HERE, "posemb.npz"), **out)
+    print("posemb ok")
+
+
+def gen_tiny_e2e():
+    cfg = O.tiny_cfg()
+    sd = G.perturbed_state(cfg, seed=7)
+    model = build_ref_model(cfg)
+    missing = model.load_state_dict(sd, strict=True)
+    x = G.seeded_inputs(cfg, B=2, seed=3)
+    k = 8
+    n = (cfg["image"] // cfg["patch"]) ** 2
+    seed = 5
+    p, noises, noise_all = replay_mask_rng(seed, 2, [n, n], 1.0, False)
+    G.assert_tie_free(p, noises, noise_all, k)
+    losses_fn = {"rgb": ref.MaskedMSELoss(patch_size=16, stride=1),
+                 "depth": ref.MaskedL1Loss(patch_size=16, stride=1),
+                 "norm_rgb": ref.MaskedMSELoss(patch_size=16, stride=1, norm_pix=True)}
+    tgt = {"rgb": "rgb", "depth": "depth", "norm_rgb": "rgb"}
+    out = {"k": np.int64(k), "p": p.numpy(), "noise0": noises[0].numpy(), "noise1": noises[1].numpy(),
+           "noise_all": noise_all.numpy()}
+
+    torch.manual_seed(seed)
+    model.zero_grad()
+    preds, masks = model(x, num_encoded_tokens=k, alphas=1.0)
+    losses = {t: losses_fn[t](preds[t].float(), x[tgt[t]], mask=masks[tgt[t]]) for t in preds}
+    sum(losses.values()).backward()
+    named = dict(model.named_parameters())
+    for t in preds:
+        out[f"pred_{t}"] = preds[t].detach().numpy()
+        out[f"loss_{t}"] = losses[t].detach().numpy()
+    for d in masks:
+        out[f"mask_{d}"] = masks[d].numpy().astype(np.uint8)
+    for name in G.TINY_GRAD_NAMES:
+        out["grad_" + name] = named[name].grad.numpy()
+    # global gradient norm over all trainable parameters
+    out["grad_norm"] = torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in named.values() if p_.grad is not None)).numpy()
+    out["n_state_keys"] = np.int64(len(model.state_dict()))
+
+    # the same step under bf16 autocast (the reference's AMP semantics with bf16 as the dtype)
+    torch.manual_seed(seed)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        preds_b, masks_b = model(x, num_encoded_tokens=k, alphas=1.0)
+    for t in preds_b:
+        out[f"bf16_loss_{t}"] = losses_fn[t](preds_b[t].float(), x[tgt[t]], mask=masks_b[tgt[t]]).detach().numpy()
+    out["bf16_pred_depth"] = preds_b["depth"].float().detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "tiny_e2e.npz"), **out)
+    print("tiny e2e ok; losses", {t: float(v) for t, v in losses.items()})
+
+
+def gen_losses():
+    out = {}
+    g = torch.Generator().manual_seed(21)
+
+    def run(tag, fn, pred, target, mask):
+        pred = pred.clone().requires_grad_(True)
+        loss = fn(pred, target, mask=mask)
+        out[tag + "_loss"] = loss.detach().numpy()
+        if loss.requires_grad:
+            loss.backward()
+            out[tag + "_dpred"] = pred.grad.numpy()
+        out[tag + "_pred"] = pred.detach().numpy()
+        out[tag + "_target"] = target.numpy()
+        if mask is not None:
+            out[tag + "_mask"] = mask.numpy().astype(np.uint8)
+
+    B, H = 2, 32  # patch 16 -> 2x2 patches
+    for C, tagc in ((3, "c3"), (1, "c1")):
+        pred = torch.randn(B, C, H, H, generator=g)
+        target = torch.randn(B, C, H, H, generator=g)
+        mask = torch.tensor([[1, 0, 1, 1], [0, 0, 1, 0]])
+        run(f"mse_{tagc}", ref.MaskedMSELoss(16, 1), pred, target, mask)
+        run(f"l1_{tagc}", ref.MaskedL1Loss(16, 1), pred, target, mask)
+        run(f"msenp_{tagc}", ref.MaskedMSELoss(16, 1, norm_pix=True), pred, target, mask)
+        run(f"l1np_{tagc}", ref.MaskedL1Loss(16, 1, norm_pix=True), pred, target, mask)
+        # a sample with no masked token: 0/0 for that sample, dropped by nanmean
+        mask0 = torch.tensor([[0, 0, 0, 0], [0, 1, 1, 0]])
+        run(f"mse_rowzero_{tagc}", ref.MaskedMSELoss(16, 1), pred, target, mask0)
+        # nothing masked at all: int64 zero
+        run(f"mse_allzero_{tagc}", ref.MaskedMSELoss(16, 1), pred, target, torch.zeros(B, 4, dtype=torch.long))
+        run(f"mse_nomask_{tagc}", ref.MaskedMSELoss(16, 1), pred, target, None)
+        run(f"l1_nomask_{tagc}", ref.MaskedL1Loss(16, 1), pred, target, None)
+    # cross entropy: 5 classes, stride 4 -> scale 4, 16x16 map = 4x4 patches
+    logits = torch.randn(B, 5, 16, 16, generator=g)
+    tgt = torch.randint(0, 5, (B, 16, 16), generator=g)
+    mask = (torch.rand(B, 16, generator=g) > 0.4).long()
+    run("ce", ref.MaskedCrossEntropyLoss(16, 4), logits, tgt, mask)
+    run("ce_ls", ref.MaskedCrossEntropyLoss(16, 4, label_smoothing=0.1), logits, tgt, mask)
+    run("ce_nomask", ref.MaskedCrossEntropyLoss(16, 4), logits, tgt, None)
+    np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
+    print("losses ok")
+
+
+def gen_blocks():
+    out = {}
+    from functools import partial
+    g = torch.Generator().manual_seed(33)
+    # Block(64, 4 heads), N=99, B=2
+    sd = G.perturbed_block_state("blk", 64, 256, seed=41)
+    blk = RefBlock(dim=64, num_heads=4, mlp_ratio=4.0, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
+    blk.load_state_dict({k[len("blk."):]: v for k, v in sd.items()}, strict=True)
+    x = torch.randn(2, 99, 64, generator=g).requires_grad_(True)
+    dy = torch.randn(2, 99, 64, generator=g)
+    y = blk(x)
+    y.backward(dy)
+    out["block_x"] = x.detach().numpy(); out["block_dy"] = dy.numpy()
+    out["block_y"] = y.detach().numpy(); out["block_dx"] = x.grad.numpy()
+    out["block_dqkv_w"] = blk.attn.qkv.weight.grad.numpy()
+    out["block_dfc1_b"] = blk.mlp.fc1.bias.grad.numpy()
+    out["block_dnorm1_w"] = blk.norm1.weight.grad.numpy()
+    # CrossAttention(32, 4 heads), Nq=196, Nctx=99
+    sdx = G.perturbed_xattn_state("xa", 32, seed=43)
+    xa = RefXAttn(dim=32, num_heads=4, qkv_bias=True)
+    xa.load_state_dict({k[len("xa."):]: v for k, v in sdx.items()}, strict=True)
+    q = torch.randn(2, 196, 32, generator=g).requires_grad_(True)
+    c = torch.randn(2, 99, 32, generator=g).requires_grad_(True)
+    dy = torch.randn(2, 196, 32, generator=g)
+    y = xa(q, c)
+    y.backward(dy)
+    out["xa_q"] = q.detach().numpy(); out["xa_c"] = c.detach().numpy(); out["xa_dy"] = dy.numpy()
+    out["xa_y"] = y.detach().numpy(); out["xa_dq"] = q.grad.numpy(); out["xa_dc"] = c.grad.numpy()
+    out["xa_dkv_w"] = xa.kv.weight.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "blocks.npz"), **out)
+    print("blocks ok")
+
+
+def gen_depth_std():
+    # The reference applies this inline in its training loop (run_pretraining_multimae.py:448-459),
+    # which is not importable; the three statements are replayed here with the same torch/einops calls.
+    from einops import rearrange
+    g = torch.Generator().manual_seed(55)
+    depth = torch.rand(2, 1, 32, 32, generator=g) * 7.0
+    trunc = torch.sort(rearrange(depth, "b c h w -> b (c h w)"), dim=1)[0]
+    trunc = trunc[:, int(0.1 * trunc.shape[1]): int(0.9 * trunc.shape[1])]
+    res = (depth - trunc.mean(dim=1)[:, None, None, None]) / torch.sqrt(trunc.var(dim=1)[:, None, None, None] + 1e-6)
+    np.savez_compressed(os.path.join(HERE, "depth_std.npz"), depth=depth.numpy(), out=res.numpy())
+    print("depth std ok")
+
+
+if __name__ == "__main__":
+    gen_masks()
+    gen_posemb()
+    gen_tiny_e2e()
+    gen_losses()
+    gen_blocks()
+    gen_depth_std()
