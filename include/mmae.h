@@ -1,0 +1,175 @@
+/* libmmae_hip.so -- C ABI of the MI355X (gfx950) kernels behind the MultiMAE pretraining step.
+ *
+ * The reference (thinh-re/multimae) is pure PyTorch: its hot path is sequences of ATen ops inside
+ * nn.Modules.  Each entry point below replaces one such sequence; the comment on each cites the
+ * reference lines it stands for (paths relative to the reference tree).  The Python package
+ * multimae_amd binds these with ctypes and wraps them in autograd Functions behind the
+ * reference's module API.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - calls only enqueue work on `stream`; they never allocate, free or synchronise;
+ *   - return 0 (MMAE_OK) or a negative MMAE_E* code; mmae_last_error() gives the message of the
+ *     calling thread's last failure;
+ *   - bf16 tensors are row-major with explicit row strides counted in elements; 16-byte aligned.
+ */
+#ifndef MMAE_H
+#define MMAE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* mmae_stream_t; /* == hipStream_t */
+
+enum {
+    MMAE_OK = 0,
+    MMAE_EINVAL = -1,     /* null pointer / bad argument */
+    MMAE_ESHAPE = -2,     /* shape or stride the kernels do not support */
+    MMAE_EWORKSPACE = -3, /* workspace too small */
+    MMAE_ELAUNCH = -4,    /* HIP reported a launch error */
+};
+
+const char* mmae_last_error(void);
+int mmae_version(void);
+
+/* ---- GEMM family --------------------------------------------------------------------------
+ * mmae_gemm_nt: C[M,N] = A[M,K] x W[N,K]^T with a fused epilogue.  Replaces nn.Linear forward
+ * (multimae/multimae_utils.py:163,167,194,205,229,234,245; output_adapters.py:341,361) and, fed with a
+ * transposed weight copy, the dA = dC x W half of its backward.
+ *   epi 0  out(bf16) = acc + bias                               (qkv, q, kv, proj_context, dA)
+ *   epi 1  out(bf16) = h = acc + bias, out2(bf16) = gelu_erf(h) (Mlp.fc1 + nn.GELU, :163-164)
+ *   epi 2  out(f32)  = aux(f32) + acc + bias                    (attn.proj / Mlp.fc2 + residual, :283-284)
+ *   epi 3  out(bf16) = acc * gelu_erf'(aux(bf16))               (backward through nn.GELU)
+ *   epi 4  out(f32)  = acc + bias
+ * K must be a multiple of 8, N of 4; bias may be NULL for epi 0/3/4. */
+int mmae_gemm_nt(int epi, const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,
+                 void* out, long ldo, void* out2, const void* aux, long ldaux, mmae_stream_t stream);
+
+/* Patch projection of the kept tokens only: out[(m/seg_in)*seg_out + m%seg_in] = A[m] x W^T + add_tab[add_idx[m]]
+ * where A holds the packed patches (mmae_pack_patches), W the per-domain Conv2d weights concatenated along K
+ * and add_tab = pos_emb + conv bias per (domain, position).  Replaces Conv2d(k=s=P) + rearrange +
+ * pos-emb add + gather(ids_keep) (multimae/input_adapters.py:126-135, multimae/multimae.py:393-402). */
+int mmae_patch_embed_gemm(const void* A, const void* W, int M, int N, int K, const int* add_idx, const float* add_tab,
+                          int seg_in, int seg_out, float* out, long ldo, mmae_stream_t stream);
+
+/* out_proj + "b (nh nw) (c ph pw) -> b c (nh ph) (nw pw)" store (multimae/output_adapters.py:361-372);
+ * out_image is bf16 [M/(NH*NW), C, NH*P, NW*P]. */
+int mmae_unpatchify_gemm(const void* A, long lda, const void* W, int M, int N, int K, const float* bias,
+                         void* out_image, int C, int P, int NH, int NW, mmae_stream_t stream);
+
+/* mmae_gemm_tn: out[N,K] (f32) (+)= X[M,N]^T x Y[M,K]: the weight-gradient half of nn.Linear backward
+ * (dW = dC^T x A).  Split over M into fp32 slabs held in `workspace`, then reduced in a fixed order
+ * (bitwise reproducible). */
+size_t mmae_gemm_tn_workspace_bytes(int M, int N, int K);
+int mmae_gemm_tn(const void* X, long ldx, const void* Y, long ldy, int M, int N, int K, float* out, int accumulate,
+                 void* workspace, size_t workspace_bytes, mmae_stream_t stream);
+
+/* Column sums of a bf16 matrix: bias gradient of nn.Linear. */
+size_t mmae_colsum_workspace_bytes(int M, int N);
+int mmae_colsum_bf16(const void* X, long ldx, int M, int N, float* out, int accumulate, void* workspace,
+                     size_t workspace_bytes, mmae_stream_t stream);
+
+/* ---- LayerNorm (eps 1e-6; multimae/multimae_utils.py:283-284, output_adapters.py:350-353) ---------
+ * fwd: y(bf16) = LN(x(f32)) * gamma + beta; saves mean and rstd per row.
+ * bwd: dx(f32) = (dres ? dres : 0) + LN'(dy(bf16)); optional bf16 copy of dx; dgamma/dbeta are
+ *      written as per-block partial rows into `workspace` and summed by a second kernel. */
+int mmae_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean, float* rstd,
+                       int rows, int dim, float eps, mmae_stream_t stream);
+size_t mmae_layernorm_bwd_workspace_bytes(int rows, int dim);
+int mmae_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
+                       const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta, int accumulate,
+                       int rows, int dim, void* workspace, size_t workspace_bytes, mmae_stream_t stream);
+
+/* ---- attention (multimae/multimae_utils.py:200-204 and :240-244) ----------------------------
+ * softmax(q k^T * scale) v per (batch, head) without materialising the scores.  q/k/v/o rows are
+ * addressed as base + (b*len + i)*ld + h*head_dim, so the packed [B,N,3,H,d] qkv buffer and the
+ * [B,M,2,H,d] kv buffer are read in place.  head_dim in {32, 64}; forward: K/V of one head must fit 160 KiB of LDS (kv_len <= 576 at head_dim 64);
+ * backward: q_len, kv_len <= 128 at head_dim 64, <= 224 at head_dim 32.
+ * fwd also writes lse[B,H,q_len] (f32, natural log) for the backward. */
+int mmae_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
+                  float* lse, int B, int H, int q_len, int kv_len, int head_dim, float scale, mmae_stream_t stream);
+int mmae_attn_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* o, long ldo,
+                  const void* d_o, long lddo, const float* lse, void* dq, long lddq, void* dk, long lddk, void* dv,
+                  long lddv, int B, int H, int q_len, int kv_len, int head_dim, float scale, mmae_stream_t stream);
+
+/* ---- masking (multimae/multimae.py:218-253) --------------------------------------------------
+ * One workgroup per sample.  task_dist [B,T] f32 is the Dirichlet sample, noise [B,total] f32 the
+ * per-task noise tensors concatenated in task order, noise_all [B,total] f32 the second draw.
+ * Outputs: ids_keep [B,k] i64, ids_restore [B,total] i64, mask [B,total] i64 (0 keep / 1 masked,
+ * split per task by the caller), plus i32 copies of ids_keep / ids_restore for the gather kernels.
+ * Ties sort lower index first.  T <= 8, tokens per task <= 1024, total <= 2048. */
+int mmae_mask_generate(const float* task_dist, const float* noise, const float* noise_all, const int* tokens_per_task_host,
+                       int T, int B, int num_encoded, int64_t* ids_keep, int64_t* ids_restore, int64_t* mask,
+                       int* ids_keep_i32, int* ids_restore_i32, mmae_stream_t stream);
+
+/* ---- token plumbing ------------------------------------------------------------------------- */
+/* Pack the kept patches as bf16 rows of the K-concatenated patch matrix:
+ * row (b*k + j) = [0 .. | patch (c,ph,pw) of token ids_keep[b,j] in its domain's column block | .. 0].
+ * images_host: T device pointers to f32 [B,C_t,H,W] passed by value in a host array. */
+int mmae_pack_patches(const float* const* images_host, const int* channels_host, int T, int B, int H, int W, int P,
+                      const int* ids_keep_i32, int k, void* out_bf16, int Ktot, mmae_stream_t stream);
+/* The column block after the patches holds one-hot(domain) so that the weight-gradient GEMM over the packed
+ * rows also yields the per-domain Conv2d bias gradient; Ktot >= sum_t C_t*P*P + 8, a multiple of 64. */
+
+/* add_tab[t*ntok + pos][:] = pos_emb_t[:, pos] + bias_t   (multimae/input_adapters.py:129-135) */
+int mmae_build_token_table(const float* const* pos_emb_host, const float* const* bias_host, int T, int ntok, int dim,
+                           float* add_tab, mmae_stream_t stream);
+/* x[b, k + g, :] = global_tokens[g, :]  (multimae/multimae.py:405-406); rows are seq = k + G long */
+int mmae_append_global(const float* global_tokens, float* x, int B, int k, int G, int dim, mmae_stream_t stream);
+/* d_global[g,:] = sum_b dx[b, k+g, :] and dx_bf16_rows[b*k + j, :] = bf16(dx[b, j, :]) (input of the weight-gradient GEMM) */
+int mmae_embed_bwd_reduce(const float* dx, const int* ids_keep_i32, int B, int k, int G, int dim, int T, int ntok,
+                          float* d_global, float* const* d_bias_host, void* dx_bf16_rows, mmae_stream_t stream);
+
+/* Decoder input assembly (multimae/output_adapters.py:195-314): from ctx = proj_context(encoder tokens)
+ * (bf16 [B, k+G, Dd]) build queries f32 [B, ntok, Dd] (own-task slice of the un-shuffled, mask-token-filled,
+ * embedded sequence) and context f32 [B, k+G, Dd] (kept tokens + embeddings, global tokens appended raw).
+ * emb is f32 [total, Dd] = task_embedding[t] + pos_emb[pos]. */
+int mmae_decoder_assemble_fwd(const void* ctx_bf16, const float* mask_token, const float* emb, const int* ids_keep_i32,
+                              const int* ids_restore_i32, int B, int k, int G, int total, int q_start, int q_len, int Dd,
+                              float* queries, float* context, mmae_stream_t stream);
+/* Gradients of the assembly: d_ctx bf16 [B,k+G,Dd]; d_mask_token f32 [Dd]; d_task_emb_host[t] f32 [Dd]
+ * (sum over the positions of task t of the embedding gradient; pos_emb is frozen). Tasks have ntok tokens each. */
+size_t mmae_decoder_assemble_bwd_workspace_bytes(int B, int T, int Dd);
+int mmae_decoder_assemble_bwd(const float* d_queries, const float* d_context, const int* ids_keep_i32,
+                              const int* ids_restore_i32, int B, int k, int G, int T, int ntok, int q_start, int q_len,
+                              int Dd, void* d_ctx_bf16, float* d_mask_token, float* const* d_task_emb_host,
+                              void* workspace, size_t workspace_bytes, mmae_stream_t stream);
+/* emb[t*ntok + pos][:] = task_emb_t[:] + pos_emb[:, pos]  (multimae/output_adapters.py:195-228) */
+int mmae_build_decoder_emb(const float* const* task_emb_host, const float* pos_emb, int T, int ntok, int Dd, float* emb,
+                           mmae_stream_t stream);
+
+/* image (bf16 [B,C,H,W]) -> token rows (bf16 [B*NH*NW, C*P*P]): the adjoint of the un-patchify store */
+int mmae_patchify_bf16(const void* image, int B, int C, int NH, int NW, int P, void* rows, mmae_stream_t stream);
+
+/* ---- masked losses (multimae/criterion.py:96-130, :161-195) ----------------------------------
+ * kind 0 = MSE, 1 = L1; norm_pix standardises each target patch over (p1 p2 c) with unbiased variance.
+ * pred is bf16 or f32 [B,C,H,W] (pred_is_bf16), target f32, mask i64 [B, nh*nw] or NULL.
+ * Writes loss (f32 scalar, nanmean over samples of masked-mean error) and, if d_pred != NULL, the
+ * gradient of the loss w.r.t. pred in pred's dtype.  workspace: mmae_masked_loss_workspace_bytes(B). */
+size_t mmae_masked_loss_workspace_bytes(int B, int C, int H, int W, int patch);
+int mmae_masked_loss(int kind, int norm_pix, const void* pred, int pred_is_bf16, const float* target, const int64_t* mask,
+                     int B, int C, int H, int W, int patch, float* loss, void* d_pred, void* workspace,
+                     size_t workspace_bytes, mmae_stream_t stream);
+
+/* ---- optimiser step over flat buffers (AdamW; run_pretraining_multimae_v2.py:339-344) -----------
+ * p, g, m, v are f32 [n]; elements [0, n_decay) use weight_decay, the rest none.
+ * grad_scale multiplies g first (1/world_size for the data-parallel mean, clip factor).
+ * If w_bf16 != NULL the updated parameters are also written there as bf16. */
+int mmae_adamw_flat(float* p, const float* g, float* m, float* v, long n, long n_decay, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, float grad_scale, void* w_bf16,
+                    mmae_stream_t stream);
+/* sum of squares of f32 [n] into out[0] (f32); partials in workspace (>= 4096 bytes) */
+int mmae_sumsq(const float* x, long n, float* out, void* workspace, size_t workspace_bytes, mmae_stream_t stream);
+/* dst(bf16)[rows, cols] = src(f32)[rows, cols]; dst_t(bf16)[cols, rows] = transpose (either may be NULL) */
+int mmae_cast_transpose(const float* src, int rows, int cols, void* dst_bf16, void* dst_t_bf16, mmae_stream_t stream);
+/* y(bf16) = x(f32) elementwise */
+int mmae_cast_bf16(const float* x, void* y_bf16, long n, mmae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMAE_H */

@@ -1,0 +1,81 @@
+// Shared device/host helpers for the MultiMAE gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/mmae.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define MMAE_WAVE 64
+
+// ---- error reporting (thread-local message, negative return codes) -------------------
+void mmae_set_error(const char* fmt, ...);
+
+#define MMAE_REQUIRE(cond, code, ...)            \
+    do {                                         \
+        if (!(cond)) {                           \
+            mmae_set_error(__VA_ARGS__);         \
+            return (code);                       \
+        }                                        \
+    } while (0)
+
+#define MMAE_CHECK_LAUNCH(name)                                                   \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            mmae_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return MMAE_ELAUNCH;                                                  \
+        }                                                                         \
+    } while (0)
+
+// ---- device helpers --------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Sum over a 256..1024-thread block; every thread gets the result. `red` holds >= 16 floats.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// async 16-byte global -> LDS copy; `lds_wave_base` must be wave-uniform, lane i lands at +16*i
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// XCD-aware block id remap: blocks id, id+8, ... share an XCD (and its L2); give each of the
+// 8 groups a contiguous run of logical ids so neighbouring tiles reuse operand panels in L2.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7, x = id & 7, j = id >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}

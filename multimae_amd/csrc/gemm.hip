@@ -1,0 +1,467 @@
+// bf16 MFMA GEMMs for the MultiMAE step (gfx950).
+//
+//  gemm_nt : C[M,N] = A[M,K] * W[N,K]^T  (+ fused epilogue)      forward Linear, dA = dC * W via W^T copy
+//  gemm_tn : D[N,K] = X[M,N]^T * Y[M,K]                           dW = dC^T * A, split over M into fp32 slabs
+//
+// Both use 128x128 output tiles, four waves (2x2, 64x64 each), v_mfma_f32_16x16x32_bf16,
+// 16-byte global->LDS DMA into a double-buffered, XOR-swizzled LDS image.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BKT 64            // k elements per stage
+#define TILE_BYTES 16384  // 128 rows x 64 bf16
+
+__device__ uint4 g_zero_page[4];  // 64 bytes of zeros: DMA source for out-of-range rows / k chunks
+
+enum {
+    EPI_BF16 = 0,      // out bf16 = acc (+bias)
+    EPI_GELU = 1,      // out bf16 = h = acc+bias ; out2 bf16 = gelu(h)
+    EPI_RESID = 2,     // out f32 = aux_f32 + acc + bias
+    EPI_DGELU = 3,     // out bf16 = acc * gelu'(aux_bf16)
+    EPI_F32 = 4,       // out f32 = acc (+bias)
+    EPI_TOKENS = 5,    // out f32[row_map(m)] = acc + add_tab[add_idx[m]]   (patch embed)
+    EPI_UNPATCH = 6,   // out bf16 image[b,c,nh*P+ph,nw*P+pw] = acc + bias   (out_proj)
+};
+
+struct GemmNT {
+    const bf16* A; long lda;
+    const bf16* W; long ldw;
+    int M, N, K;
+    const float* bias;
+    void* out; long ldo;
+    void* out2;
+    const void* aux; long ldaux;
+    int seg_in, seg_out;        // EPI_TOKENS: out row = (m / seg_in) * seg_out + m % seg_in
+    const int* add_idx; const float* add_tab;
+    int C, P, NH, NW;           // EPI_UNPATCH
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int nblk = gridDim.x;
+    const int wg = xcd_remap(blockIdx.x, nblk);
+    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+
+    // staging: wave-instruction j of this wave fills LDS rows (j*4+wave)*8 .. +7 (8 lanes per 128-B row)
+    const bf16* a_src[4];
+    const bf16* w_src[4];
+    int k_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (j * 4 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);  // source chunk so that LDS holds chunk^swz linearly
+        int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
+        int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
+        a_src[j] = p.A + (long)gm * p.lda + c * 8;
+        w_src[j] = p.W + (long)gn * p.ldw + c * 8;
+        k_src[j] = c * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* sa = smem + buf * 2 * TILE_BYTES;
+        char* sw = sa + TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in_k = kt * BKT + k_src[j] < p.K;  // chunks past K read zeros (K need not be a multiple of 64)
+            const void* as = in_k ? (const void*)(a_src[j] + kt * BKT) : (const void*)g_zero_page;
+            const void* ws = in_k ? (const void*)(w_src[j] + kt * BKT) : (const void*)g_zero_page;
+            glds16(as, sa + (j * 4 + wave) * 1024);
+            glds16(ws, sw + (j * 4 + wave) * 1024);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BKT - 1) / BKT;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int swz = fr >> 1;  // (row>>1)&7 with row = 16*t + fr
+    stage(0, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sa = smem + cur * 2 * TILE_BYTES;
+        const char* sw = sa + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = ((ks * 4 + fq) ^ swz) << 4;
+            bf16x8 wf[4], af[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                wf[t] = *(const bf16x8*)(sw + (wn * 64 + t * 16 + fr) * 128 + chunk);
+                af[t] = *(const bf16x8*)(sa + (wm * 64 + t * 16 + fr) * 128 + chunk);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: acc[ni][mi][r] = C[m = m0+wm*64+mi*16+fr][n = n0+wn*64+ni*16+fq*4+r]
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 64 + mi * 16 + fr;
+        if (m >= p.M) continue;
+        long orow = m;
+        const float* tab = nullptr;
+        int ib = 0, inh = 0, inw = 0;
+        if (EPI == EPI_TOKENS) {
+            orow = (long)(m / p.seg_in) * p.seg_out + (m % p.seg_in);
+            tab = p.add_tab + (long)p.add_idx[m] * p.N;
+        }
+        if (EPI == EPI_UNPATCH) {
+            const int ntok = p.NH * p.NW;
+            ib = m / ntok;
+            const int t = m - ib * ntok;
+            inh = t / p.NW; inw = t - inh * p.NW;
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + fq * 4;
+            if (n >= p.N) continue;
+            f32x4 v = acc[ni][mi];
+            if (EPI != EPI_DGELU && EPI != EPI_TOKENS && p.bias) {
+                const f32x4 b = *(const f32x4*)(p.bias + n);
+                v += b;
+            }
+            if (EPI == EPI_BF16) {
+                bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                *(bf16x4*)((bf16*)p.out + orow * p.ldo + n) = o;
+            } else if (EPI == EPI_GELU) {
+                bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                bf16x4 g = {(bf16)gelu_erf((float)h[0]), (bf16)gelu_erf((float)h[1]),
+                            (bf16)gelu_erf((float)h[2]), (bf16)gelu_erf((float)h[3])};
+                *(bf16x4*)((bf16*)p.out + orow * p.ldo + n) = h;
+                *(bf16x4*)((bf16*)p.out2 + orow * p.ldo + n) = g;
+            } else if (EPI == EPI_RESID) {
+                const f32x4 r = *(const f32x4*)((const float*)p.aux + orow * p.ldaux + n);
+                *(f32x4*)((float*)p.out + orow * p.ldo + n) = r + v;
+            } else if (EPI == EPI_DGELU) {
+                const bf16x4 h = *(const bf16x4*)((const bf16*)p.aux + orow * p.ldaux + n);
+                bf16x4 o = {(bf16)(v[0] * gelu_erf_grad((float)h[0])), (bf16)(v[1] * gelu_erf_grad((float)h[1])),
+                            (bf16)(v[2] * gelu_erf_grad((float)h[2])), (bf16)(v[3] * gelu_erf_grad((float)h[3]))};
+                *(bf16x4*)((bf16*)p.out + orow * p.ldo + n) = o;
+            } else if (EPI == EPI_F32) {
+                *(f32x4*)((float*)p.out + orow * p.ldo + n) = v;
+            } else if (EPI == EPI_TOKENS) {
+                const f32x4 t = *(const f32x4*)(tab + n);
+                *(f32x4*)((float*)p.out + orow * p.ldo + n) = v + t;
+            } else if (EPI == EPI_UNPATCH) {
+                const int pp = p.P * p.P;
+                const int c = n / pp, rem = n - c * pp, ph = rem / p.P, pw = rem - ph * p.P;
+                const long H = (long)p.NH * p.P, Wd = (long)p.NW * p.P;
+                bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                *(bf16x4*)((bf16*)p.out + (((long)ib * p.C + c) * H + inh * p.P + ph) * Wd + inw * p.P + pw) = o;
+            }
+        }
+    }
+}
+
+template <int EPI>
+static int launch_nt(const GemmNT& p, hipStream_t s) {
+    const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+    hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(tm * tn), dim3(256), 0, s, p);
+    MMAE_CHECK_LAUNCH("gemm_nt");
+    return MMAE_OK;
+}
+
+static int check_nt(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const void* out) {
+    MMAE_REQUIRE(A && W && out, MMAE_EINVAL, "gemm_nt: null pointer");
+    MMAE_REQUIRE(M > 0 && N > 0 && K > 0, MMAE_EINVAL, "gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
+    MMAE_REQUIRE(K % 8 == 0, MMAE_ESHAPE, "gemm_nt: K=%d must be a multiple of 8", K);
+    MMAE_REQUIRE(N % 4 == 0, MMAE_ESHAPE, "gemm_nt: N=%d must be a multiple of 4", N);
+    MMAE_REQUIRE(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, MMAE_ESHAPE,
+                 "gemm_nt: row strides (lda=%ld, ldw=%ld) must be >= K and multiples of 8", lda, ldw);
+    MMAE_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0), MMAE_EINVAL, "gemm_nt: operands must be 16-byte aligned");
+    return MMAE_OK;
+}
+
+extern "C" int mmae_gemm_nt(int epi, const void* A, long lda, const void* W, long ldw, int M, int N, int K,
+                            const float* bias, void* out, long ldo, void* out2, const void* aux, long ldaux,
+                            hipStream_t stream) {
+    int rc = check_nt(A, lda, W, ldw, M, N, K, out);
+    if (rc) return rc;
+    GemmNT p = {};
+    p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
+    p.bias = bias; p.out = out; p.ldo = ldo; p.out2 = out2; p.aux = aux; p.ldaux = ldaux;
+    MMAE_REQUIRE(ldo >= N && ldo % 4 == 0, MMAE_ESHAPE, "gemm_nt: ldo=%ld must be >= N and a multiple of 4", ldo);
+    switch (epi) {
+        case EPI_BF16: return launch_nt<EPI_BF16>(p, stream);
+        case EPI_GELU:
+            MMAE_REQUIRE(out2 && bias, MMAE_EINVAL, "gemm_nt(gelu): needs bias and a second output");
+            return launch_nt<EPI_GELU>(p, stream);
+        case EPI_RESID:
+            MMAE_REQUIRE(aux && ldaux >= N, MMAE_EINVAL, "gemm_nt(resid): needs the residual input");
+            return launch_nt<EPI_RESID>(p, stream);
+        case EPI_DGELU:
+            MMAE_REQUIRE(aux && ldaux >= N, MMAE_EINVAL, "gemm_nt(dgelu): needs the saved pre-activation");
+            return launch_nt<EPI_DGELU>(p, stream);
+        case EPI_F32: return launch_nt<EPI_F32>(p, stream);
+        default: break;
+    }
+    mmae_set_error("gemm_nt: unknown epilogue %d", epi);
+    return MMAE_EINVAL;
+}
+
+extern "C" int mmae_patch_embed_gemm(const void* A, const void* W, int M, int N, int K, const int* add_idx,
+                                     const float* add_tab, int seg_in, int seg_out, float* out, long ldo,
+                                     hipStream_t stream) {
+    int rc = check_nt(A, K, W, K, M, N, K, out);
+    if (rc) return rc;
+    MMAE_REQUIRE(add_idx && add_tab && seg_in > 0 && seg_out >= seg_in, MMAE_EINVAL, "patch_embed_gemm: bad row map");
+    GemmNT p = {};
+    p.A = (const bf16*)A; p.lda = K; p.W = (const bf16*)W; p.ldw = K; p.M = M; p.N = N; p.K = K;
+    p.out = out; p.ldo = ldo; p.seg_in = seg_in; p.seg_out = seg_out; p.add_idx = add_idx; p.add_tab = add_tab;
+    return launch_nt<EPI_TOKENS>(p, stream);
+}
+
+extern "C" int mmae_unpatchify_gemm(const void* A, long lda, const void* W, int M, int N, int K, const float* bias,
+                                    void* out_image, int C, int P, int NH, int NW, hipStream_t stream) {
+    int rc = check_nt(A, lda, W, K, M, N, K, out_image);
+    if (rc) return rc;
+    MMAE_REQUIRE(N == C * P * P && P % 4 == 0 && M % (NH * NW) == 0, MMAE_ESHAPE,
+                 "unpatchify_gemm: N=%d must equal C*P*P (C=%d P=%d) and M=%d a multiple of NH*NW", N, C, P, M);
+    GemmNT p = {};
+    p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = K; p.M = M; p.N = N; p.K = K;
+    p.bias = bias; p.out = out_image; p.C = C; p.P = P; p.NH = NH; p.NW = NW;
+    return launch_nt<EPI_UNPATCH>(p, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// gemm_tn: D[N,K] = sum_m X[m,N] * Y[m,K]; both operands are m-major (their rows are the
+// reduction index), so fragments are fetched with the transposing LDS read.
+// ------------------------------------------------------------------------------------------
+#define TN_ROWS 64  // m rows per stage; tile image is [64][128] bf16 = 16 KiB, 256-B rows
+
+struct GemmTN {
+    const bf16* X; long ldx;  // [M,N]
+    const bf16* Y; long ldy;  // [M,K]
+    int M, N, K;
+    int rows_per_split;       // multiple of TN_ROWS
+    float* out;               // [splits][N][K] slabs (or the final [N,K] when splits == 1)
+    long slab;                // elements per slab
+};
+
+__device__ __forceinline__ int tn_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;  // wave tile: 64 n x 64 k
+    const int tiles_k = (p.K + 127) / 128;
+    const int nblk = gridDim.x;
+    const int wg = xcd_remap(blockIdx.x, nblk);
+    const int n0 = (wg / tiles_k) * 128, k0 = (wg % tiles_k) * 128;
+    const int split = blockIdx.y;
+    const int m_begin = split * p.rows_per_split;
+    int m_end = m_begin + p.rows_per_split; m_end = m_end < p.M ? m_end : p.M;
+
+    // staging: wave-instruction j fills rows (j*4+wave)*4 .. +3 (16 lanes per 256-B row)
+    int srow[4]; int xcol[4], ycol[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (j * 4 + wave) * 4 + (lane >> 4);
+        const int c16 = lane & 15;
+        const int nb = (c16 >> 1) ^ tn_swz(r);
+        const int col = nb * 16 + (c16 & 1) * 8;
+        srow[j] = r;
+        int xc = n0 + col; xc = xc + 8 <= p.N ? xc : p.N - 8;
+        int yc = k0 + col; yc = yc + 8 <= p.K ? yc : p.K - 8;
+        xcol[j] = xc; ycol[j] = yc;
+    }
+    auto stage = [&](int buf, int mt) {
+        char* sx = smem + buf * 2 * TILE_BYTES;
+        char* sy = sx + TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = mt + srow[j];
+            const bool ok = m < m_end;
+            const void* xs = ok ? (const void*)(p.X + (long)m * p.ldx + xcol[j]) : (const void*)g_zero_page;
+            const void* ys = ok ? (const void*)(p.Y + (long)m * p.ldy + ycol[j]) : (const void*)g_zero_page;
+            glds16(xs, sx + (j * 4 + wave) * 1024);
+            glds16(ys, sy + (j * 4 + wave) * 1024);
+        }
+    };
+
+    f32x4 acc[4][4];  // [ki][ni] : D'[k = ki*16 + fq*4 + r][n = ni*16 + fr]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+    const int nsteps = (m_end - m_begin + TN_ROWS - 1) / TN_ROWS;
+    if (nsteps > 0) {
+        stage(0, m_begin);
+        __syncthreads();
+    }
+    int cur = 0;
+    for (int st = 0; st < nsteps; ++st) {
+        if (st + 1 < nsteps) stage(cur ^ 1, m_begin + (st + 1) * TN_ROWS);
+        const char* sx = smem + cur * 2 * TILE_BYTES;
+        const char* sy = sx + TILE_BYTES;
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {  // two 32-row reduction steps
+            const int r0 = ms * 32 + 8 * g + q, r1 = r0 + 4;
+            const int s0 = tn_swz(r0), s1 = tn_swz(r1);
+            bf16x8 yf[4], xf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int nbx = wn * 4 + t, nby = wk * 4 + t;
+                const bf16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(sx + r0 * 256 + ((nbx ^ s0) << 5) + pp * 8));
+                const bf16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(sx + r1 * 256 + ((nbx ^ s1) << 5) + pp * 8));
+                const bf16x4 y0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(sy + r0 * 256 + ((nby ^ s0) << 5) + pp * 8));
+                const bf16x4 y1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(sy + r1 * 256 + ((nby ^ s1) << 5) + pp * 8));
+                xf[t] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+                yf[t] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[ki], xf[ni], acc[ki][ni], 0, 0, 0);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float* out = p.out + (long)split * p.slab;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + i16;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int ki = 0; ki < 4; ++ki) {
+            const int k = k0 + wk * 64 + ki * 16 + g * 4;
+            if (k >= p.K) continue;
+            *(f32x4*)(out + (long)n * p.K + k) = acc[ki][ni];
+        }
+    }
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i]
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab, int nsplit, float* __restrict__ out,
+                                   long n4, int accumulate) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 s = accumulate ? ((const f32x4*)out)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nsplit; ++k) s += ((const f32x4*)(slabs + k * slab))[i];
+        ((f32x4*)out)[i] = s;
+    }
+}
+
+static int tn_splits(int M, int N, int K) {
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    int s = (640 + tiles - 1) / tiles;           // aim for ~2.5 workgroups per CU
+    const int max_s = (M + 4 * TN_ROWS - 1) / (4 * TN_ROWS);  // at least 256 rows per split
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    return s;
+}
+
+extern "C" size_t mmae_gemm_tn_workspace_bytes(int M, int N, int K) {
+    return (size_t)tn_splits(M, N, K) * (size_t)N * (size_t)K * sizeof(float);
+}
+
+extern "C" int mmae_gemm_tn(const void* X, long ldx, const void* Y, long ldy, int M, int N, int K, float* out,
+                            int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    MMAE_REQUIRE(X && Y && out, MMAE_EINVAL, "gemm_tn: null pointer");
+    MMAE_REQUIRE(M > 0 && N >= 8 && K >= 8, MMAE_EINVAL, "gemm_tn: bad problem M=%d N=%d K=%d", M, N, K);
+    MMAE_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= N && ldy >= K, MMAE_ESHAPE,
+                 "gemm_tn: N, K and row strides must be multiples of 8 (N=%d K=%d ldx=%ld ldy=%ld)", N, K, ldx, ldy);
+    MMAE_REQUIRE(((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0) && ((uintptr_t)out % 16 == 0), MMAE_EINVAL,
+                 "gemm_tn: pointers must be 16-byte aligned");
+    const int s = tn_splits(M, N, K);
+    const bool direct = (s == 1 && !accumulate);
+    const size_t need = direct ? 0 : (size_t)s * N * K * sizeof(float);
+    MMAE_REQUIRE(workspace_bytes >= need && (need == 0 || workspace), MMAE_EWORKSPACE,
+                 "gemm_tn: workspace %zu bytes < required %zu", workspace_bytes, need);
+    GemmTN p = {};
+    p.X = (const bf16*)X; p.ldx = ldx; p.Y = (const bf16*)Y; p.ldy = ldy; p.M = M; p.N = N; p.K = K;
+    int rps = (M + s - 1) / s; rps = (rps + TN_ROWS - 1) / TN_ROWS * TN_ROWS;
+    p.rows_per_split = rps;
+    p.slab = (long)N * K;
+    float* tmp = direct ? out : (float*)workspace;
+    p.out = tmp;
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, s), dim3(256), 0, stream, p);
+    MMAE_CHECK_LAUNCH("gemm_tn");
+    if (!direct) {
+        const long n4 = (long)N * K / 4;
+        int blocks = (int)((n4 + 255) / 256); blocks = blocks > 2048 ? 2048 : blocks;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, tmp, p.slab, s, out, n4, accumulate);
+        MMAE_CHECK_LAUNCH("slab_reduce");
+    }
+    return MMAE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// column sums of a bf16 [M,N] matrix (bias gradients): two deterministic passes.
+// ------------------------------------------------------------------------------------------
+#define CS_CHUNKS 64
+__global__ void colsum_partial_kernel(const bf16* __restrict__ X, long ldx, int M, int N, float* __restrict__ part) {
+    // block: 32 column-groups of 8 columns (256 columns) x 8 row lanes
+    __shared__ float red[8][256];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int col = blockIdx.x * 256 + cg * 8;
+    const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rows_per;
+    int r1 = r0 + rows_per; r1 = r1 < M ? r1 : M;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (col < N) {
+        for (int r = r0 + rl; r < r1; r += 8) {
+            const bf16x8 v = *(const bf16x8*)(X + (long)r * ldx + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = s[e];
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (blockIdx.x * 256 + c < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r][c];
+        part[(long)blockIdx.y * N + blockIdx.x * 256 + c] = t;
+    }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int chunks, int N, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float t = accumulate ? out[c] : 0.f;
+    for (int k = 0; k < chunks; ++k) t += part[(long)k * N + c];
+    out[c] = t;
+}
+
+extern "C" size_t mmae_colsum_workspace_bytes(int M, int N) { (void)M; return (size_t)CS_CHUNKS * N * sizeof(float); }
+
+extern "C" int mmae_colsum_bf16(const void* X, long ldx, int M, int N, float* out, int accumulate, void* workspace,
+                                size_t workspace_bytes, hipStream_t stream) {
+    MMAE_REQUIRE(X && out && workspace, MMAE_EINVAL, "colsum: null pointer");
+    MMAE_REQUIRE(N % 8 == 0 && ldx % 8 == 0 && M > 0, MMAE_ESHAPE, "colsum: N=%d and ldx=%ld must be multiples of 8", N, ldx);
+    MMAE_REQUIRE(workspace_bytes >= mmae_colsum_workspace_bytes(M, N), MMAE_EWORKSPACE, "colsum: workspace too small");
+    int chunks = CS_CHUNKS; if (chunks > (M + 63) / 64) chunks = (M + 63) / 64;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, chunks), dim3(256), 0, stream, (const bf16*)X, ldx, M, N,
+                       (float*)workspace);
+    MMAE_CHECK_LAUNCH("colsum_partial");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)workspace, chunks, N,
+                       out, accumulate);
+    MMAE_CHECK_LAUNCH("colsum_final");
+    return MMAE_OK;
+}

@@ -1,0 +1,181 @@
+// Masked MSE / L1 loss with optional per-patch target standardisation (multimae/criterion.py:96-130, :161-195 of
+// the reference), forward value and gradient w.r.t. the prediction in one pass.  HBM-bound:
+// per image it reads pred + target once (target three times from L2 when norm_pix) and writes d_pred.
+//
+//   loss_b = sum_{masked patches} sum_{pixels} (1/C) sum_c err  /  (P*P * nmask_b)
+//   loss   = mean of loss_b over the samples with nmask_b > 0 (nanmean); 0 if no token is masked at all
+//   d_pred = mask * err' / (C * P*P * nmask_b * nvalid)      (NaN for a sample with nmask_b == 0, as in the reference)
+#include "common.h"
+
+struct LossArgs {
+    const void* pred; const float* target; const int64_t* mask;
+    int B, C, H, W, P, nh, nw;
+    int kind, norm_pix, pred_bf16;
+    float* nmask;     // [B]
+    float* perr;      // [B][nh] partial error sums (already masked, divided by C)
+    float* loss; void* d_pred;
+};
+
+__global__ void loss_count_kernel(LossArgs a) {
+    __shared__ float red[16];
+    const int b = blockIdx.x;
+    float s = 0.f;
+    const int n = a.nh * a.nw;
+    if (a.mask) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) s += (float)a.mask[(long)b * n + i];
+    } else {
+        s = threadIdx.x == 0 ? (float)n : 0.f;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) a.nmask[b] = s;
+}
+
+template <bool BF16>
+__device__ __forceinline__ f32x4 load_pred4(const void* p, long off) {
+    if (BF16) {
+        const bf16x4 v = *(const bf16x4*)((const bf16*)p + off);
+        return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+    return *(const f32x4*)((const float*)p + off);
+}
+
+// grid (nh, B); block (W/4, RR): thread (qx, ry) owns pixel quad qx of rows ry, ry+RR, ... of the C*P rows of this patch row.
+template <bool BF16>
+__global__ void loss_main_kernel(LossArgs a) {
+    __shared__ float s_part[1024];                    // one partial per thread
+    __shared__ float s_sum[64], s_sq[64], s_err[64];  // per patch column (nw <= 64)
+    __shared__ float s_nvalid;
+    const int b = blockIdx.y, ih = blockIdx.x;
+    const int qx = threadIdx.x, ry = threadIdx.y, RR = blockDim.y;
+    const int tid = ry * blockDim.x + qx, nthreads = blockDim.x * blockDim.y;
+    const int pw_idx = (qx * 4) / a.P;  // patch column of this quad
+    const int rows = a.C * a.P;
+    const float n_el = (float)(a.C * a.P * a.P);
+
+    // fixed-order sum of the partials of every patch column (bitwise reproducible)
+    auto patch_reduce = [&](float v, float* dst) {
+        __syncthreads();
+        s_part[tid] = v;
+        __syncthreads();
+        if (tid < a.nw) {
+            const int q0 = tid * (a.P / 4), q1 = q0 + a.P / 4;
+            float t = 0.f;
+            for (int y = 0; y < RR; ++y)
+                for (int q = q0; q < q1; ++q) t += s_part[y * blockDim.x + q];
+            dst[tid] = t;
+        }
+        __syncthreads();
+    };
+    if (tid == 0) {
+        float nv = 0.f;
+        for (int i = 0; i < a.B; ++i) nv += a.nmask[i] > 0.f ? 1.f : 0.f;
+        s_nvalid = nv;
+    }
+    __syncthreads();
+
+    auto off_of = [&](int r) {
+        const int c = r / a.P, ph = r - c * a.P;
+        return (((long)b * a.C + c) * a.H + ih * a.P + ph) * a.W + qx * 4;
+    };
+    float mean = 0.f, inv_std = 1.f;
+    if (a.norm_pix) {
+        float s = 0.f;
+        for (int r = ry; r < rows; r += RR) {
+            const f32x4 t = *(const f32x4*)(a.target + off_of(r));
+            s += t[0] + t[1] + t[2] + t[3];
+        }
+        patch_reduce(s, s_sum);
+        mean = s_sum[pw_idx] / n_el;
+        float q = 0.f;
+        for (int r = ry; r < rows; r += RR) {
+            const f32x4 t = *(const f32x4*)(a.target + off_of(r)) - mean;
+            q += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+        }
+        patch_reduce(q, s_sq);
+        inv_std = 1.0f / sqrtf(s_sq[pw_idx] / (n_el - 1.0f) + 1e-6f);  // unbiased variance, eps 1e-6
+    }
+
+    const float mk = a.mask ? (float)a.mask[(long)b * a.nh * a.nw + ih * a.nw + pw_idx] : 1.f;
+    const float nm = a.nmask[b];
+    // gradient scale: 1 / (C * P*P * nmask_b * nvalid); 0 * inf = NaN when this sample has no masked token
+    // and exactly 0 everywhere when no sample has one (the reference then returns a constant 0)
+    const float gscale = s_nvalid > 0.f ? (nm > 0.f ? 1.f / s_nvalid : 0.f) * (1.0f / ((float)(a.P * a.P) * nm)) / (float)a.C : 0.f;
+    float e = 0.f;
+    for (int r = ry; r < rows; r += RR) {
+        const long off = off_of(r);
+        const f32x4 p4 = load_pred4<BF16>(a.pred, off);
+        const f32x4 t4 = (*(const f32x4*)(a.target + off) - mean) * inv_std;
+        const f32x4 d = p4 - t4;
+        f32x4 g;
+        if (a.kind == 0) {
+            e += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+            g = 2.f * d;
+        } else {
+            e += fabsf(d[0]) + fabsf(d[1]) + fabsf(d[2]) + fabsf(d[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = d[j] > 0.f ? 1.f : (d[j] < 0.f ? -1.f : 0.f);
+        }
+        if (a.d_pred) {
+            g = g * (mk * gscale);
+            if (BF16) {
+                bf16x4 o = {(bf16)g[0], (bf16)g[1], (bf16)g[2], (bf16)g[3]};
+                *(bf16x4*)((bf16*)a.d_pred + off) = o;
+            } else {
+                *(f32x4*)((float*)a.d_pred + off) = g;
+            }
+        }
+    }
+    patch_reduce(e * mk, s_err);
+    if (tid == 0) {
+        float t = 0.f;
+        for (int i = 0; i < a.nw; ++i) t += s_err[i];
+        a.perr[(long)b * a.nh + ih] = t / (float)a.C;
+    }
+}
+
+__global__ void loss_final_kernel(LossArgs a) {
+    __shared__ float red[16];
+    float tot = 0.f, cnt = 0.f;
+    for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
+        const float nm = a.nmask[b];
+        if (nm > 0.f) {
+            float s = 0.f;
+            for (int i = 0; i < a.nh; ++i) s += a.perr[(long)b * a.nh + i];
+            tot += s / ((float)(a.P * a.P) * nm);
+            cnt += 1.f;
+        }
+    }
+    tot = block_sum(tot, red);
+    cnt = block_sum(cnt, red);
+    if (threadIdx.x == 0) a.loss[0] = cnt > 0.f ? tot / cnt : 0.f;
+}
+
+extern "C" size_t mmae_masked_loss_workspace_bytes(int B, int C, int H, int W, int patch) {
+    (void)C; (void)W;
+    return (size_t)B * sizeof(float) * (1 + (size_t)(H / (patch > 0 ? patch : 1)));
+}
+
+extern "C" int mmae_masked_loss(int kind, int norm_pix, const void* pred, int pred_is_bf16, const float* target,
+                                const int64_t* mask, int B, int C, int H, int W, int patch, float* loss, void* d_pred,
+                                void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    MMAE_REQUIRE(pred && target && loss && workspace, MMAE_EINVAL, "masked_loss: null pointer");
+    MMAE_REQUIRE(kind == 0 || kind == 1, MMAE_EINVAL, "masked_loss: kind %d not in {0 (MSE), 1 (L1)}", kind);
+    MMAE_REQUIRE(B > 0 && C > 0 && patch >= 4 && patch % 4 == 0 && H % patch == 0 && W % patch == 0, MMAE_ESHAPE,
+                 "masked_loss: image %dx%d must be a multiple of the patch %d (itself a multiple of 4)", H, W, patch);
+    MMAE_REQUIRE(W / 4 <= 1024 && W / patch <= 64, MMAE_ESHAPE, "masked_loss: width %d too large", W);
+    MMAE_REQUIRE(workspace_bytes >= mmae_masked_loss_workspace_bytes(B, C, H, W, patch), MMAE_EWORKSPACE, "masked_loss: workspace too small");
+    LossArgs a = {};
+    a.pred = pred; a.target = target; a.mask = mask; a.B = B; a.C = C; a.H = H; a.W = W; a.P = patch;
+    a.nh = H / patch; a.nw = W / patch; a.kind = kind; a.norm_pix = norm_pix; a.pred_bf16 = pred_is_bf16;
+    a.nmask = (float*)workspace; a.perr = a.nmask + B; a.loss = loss; a.d_pred = d_pred;
+    hipLaunchKernelGGL(loss_count_kernel, dim3(B), dim3(64), 0, stream, a);
+    MMAE_CHECK_LAUNCH("loss_count");
+    const int qx = W / 4;
+    int rr = 256 / qx; if (rr < 1) rr = 1; if (rr > C * patch) rr = C * patch;
+    if (pred_is_bf16) hipLaunchKernelGGL(loss_main_kernel<true>, dim3(a.nh, B), dim3(qx, rr), 0, stream, a);
+    else hipLaunchKernelGGL(loss_main_kernel<false>, dim3(a.nh, B), dim3(qx, rr), 0, stream, a);
+    MMAE_CHECK_LAUNCH("loss_main");
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, stream, a);
+    MMAE_CHECK_LAUNCH("loss_final");
+    return MMAE_OK;
+}

@@ -1,0 +1,171 @@
+// LayerNorm forward / backward for the fp32 residual stream (gfx950). One wave per row, the row held
+// in registers; HBM-bound: forward moves 4*dim (read) + 2*dim (bf16 write) bytes per row.
+#include "common.h"
+
+#define LN_MAXV 4  // float4 per lane: dim <= 64 * 4 * LN_MAXV = 1024
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                            int dim, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = dim >> 2;
+    const f32x4* xr = (const f32x4*)(x + (long)row * dim);
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            v[i] = xr[c];
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mu = wave_sum(s) / dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4 d = v[i] - mu;
+            q += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / dim + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    bf16* yr = y + (long)row * dim;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4 g = ((const f32x4*)gamma)[c], b = ((const f32x4*)beta)[c];
+            const f32x4 o = (v[i] - mu) * rs * g + b;
+            bf16x4 ob = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+            *(bf16x4*)(yr + c * 4) = ob;
+        }
+    }
+}
+
+// Backward. Each wave walks rows `wave_global, wave_global + total_waves, ...`, keeps its dgamma / dbeta
+// partial sums in registers, and the block writes one partial row pair to `part` at the end.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                            float* __restrict__ dx, bf16* __restrict__ dxb,
+                                                            float* __restrict__ part, int rows, int dim) {
+    __shared__ float red[4][2][64 * 4];  // per wave, per (dgamma|dbeta), one float4 column group at a time
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nv = dim >> 2;
+    f32x4 dg[LN_MAXV], db[LN_MAXV], gm[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        dg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        db[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int c = lane + i * 64;
+        gm[i] = c < nv ? ((const f32x4*)gamma)[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
+        const f32x4* xr = (const f32x4*)(x + (long)row * dim);
+        const bf16* dyr = dy + (long)row * dim;
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[LN_MAXV], g[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                const bf16x4 d4 = *(const bf16x4*)(dyr + c * 4);
+                const f32x4 d = {(float)d4[0], (float)d4[1], (float)d4[2], (float)d4[3]};
+                xh[i] = (xr[c] - mu) * rs;
+                g[i] = d * gm[i];
+                dg[i] += d * xh[i];
+                db[i] += d;
+                s1 += g[i][0] + g[i][1] + g[i][2] + g[i][3];
+                const f32x4 t = g[i] * xh[i];
+                s2 += t[0] + t[1] + t[2] + t[3];
+            }
+        }
+        const float c1 = wave_sum(s1) / dim, c2 = wave_sum(s2) / dim;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                f32x4 o = (g[i] - c1 - xh[i] * c2) * rs;
+                if (dres) o += ((const f32x4*)(dres + (long)row * dim))[c];
+                ((f32x4*)(dx + (long)row * dim))[c] = o;
+                if (dxb) {
+                    bf16x4 ob = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+                    *(bf16x4*)(dxb + (long)row * dim + c * 4) = ob;
+                }
+            }
+        }
+    }
+    // block-level reduction of the four waves' partial sums, one 64-float4 column group at a time
+    float* prow = part + (long)blockIdx.x * 2 * dim;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        __syncthreads();
+        *(f32x4*)&red[w][0][lane * 4] = dg[i];
+        *(f32x4*)&red[w][1][lane * 4] = db[i];
+        __syncthreads();
+        if (w < 2) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                f32x4 t = *(f32x4*)&red[0][w][lane * 4];
+                t += *(f32x4*)&red[1][w][lane * 4];
+                t += *(f32x4*)&red[2][w][lane * 4];
+                t += *(f32x4*)&red[3][w][lane * 4];
+                *(f32x4*)(prow + w * dim + c * 4) = t;
+            }
+        }
+    }
+}
+
+__global__ void ln_param_reduce_kernel(const float* __restrict__ part, int nblocks, int dim, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * dim) return;
+    float t = 0.f;
+    for (int b = 0; b < nblocks; ++b) t += part[(long)b * 2 * dim + c];
+    float* dst = c < dim ? dgamma + c : dbeta + (c - dim);
+    *dst = accumulate ? *dst + t : t;
+}
+
+static int ln_bwd_blocks(int rows) {
+    int b = (rows + 3) / 4;
+    return b > 512 ? 512 : b;
+}
+
+extern "C" int mmae_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                  int rows, int dim, float eps, hipStream_t stream) {
+    MMAE_REQUIRE(x && gamma && beta && y && mean && rstd, MMAE_EINVAL, "layernorm_fwd: null pointer");
+    MMAE_REQUIRE(rows > 0 && dim > 0 && dim % 4 == 0 && dim <= 256 * LN_MAXV, MMAE_ESHAPE,
+                 "layernorm_fwd: dim=%d must be a multiple of 4 and <= %d", dim, 256 * LN_MAXV);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, (bf16*)y, mean, rstd,
+                       rows, dim, eps);
+    MMAE_CHECK_LAUNCH("layernorm_fwd");
+    return MMAE_OK;
+}
+
+extern "C" size_t mmae_layernorm_bwd_workspace_bytes(int rows, int dim) {
+    return (size_t)ln_bwd_blocks(rows) * 2 * dim * sizeof(float);
+}
+
+extern "C" int mmae_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                  const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta, int accumulate,
+                                  int rows, int dim, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    MMAE_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, MMAE_EINVAL, "layernorm_bwd: null pointer");
+    MMAE_REQUIRE(rows > 0 && dim > 0 && dim % 4 == 0 && dim <= 256 * LN_MAXV, MMAE_ESHAPE,
+                 "layernorm_bwd: dim=%d must be a multiple of 4 and <= %d", dim, 256 * LN_MAXV);
+    MMAE_REQUIRE(workspace_bytes >= mmae_layernorm_bwd_workspace_bytes(rows, dim), MMAE_EWORKSPACE, "layernorm_bwd: workspace too small");
+    const int nb = ln_bwd_blocks(rows);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const bf16*)dy, x, gamma, mean, rstd, dres, dx,
+                       (bf16*)dx_bf16, (float*)workspace, rows, dim);
+    MMAE_CHECK_LAUNCH("layernorm_bwd");
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * dim + 255) / 256), dim3(256), 0, stream, (const float*)workspace, nb, dim,
+                       dgamma, dbeta, accumulate);
+    MMAE_CHECK_LAUNCH("ln_param_reduce");
+    return MMAE_OK;
+}

@@ -1,0 +1,126 @@
+// Optimiser-side kernels over flat parameter storage (gfx950): fused AdamW, gradient norm, bf16 weight copies.
+// HBM-bound: AdamW moves 28 bytes per parameter (p, g, m, v read; p, m, v written) (+2 for the bf16 copy).
+#include "common.h"
+
+__global__ void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                  float* __restrict__ v, long n4, long n_decay, float lr, float b1, float b2, float eps,
+                                  float wd, float bc1, float bc2_sqrt, float gscale, bf16* __restrict__ wb) {
+    // PyTorch AdamW: p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+    //                p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+    const float step = lr / bc1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 pp = ((f32x4*)p)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+        const f32x4 gg = ((const f32x4*)g)[i] * gscale;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = pp[e];
+            if (i * 4 + e < n_decay) x *= 1.0f - lr * wd;
+            const float m1 = b1 * mm[e] + (1.0f - b1) * gg[e];
+            const float v1 = b2 * vv[e] + (1.0f - b2) * gg[e] * gg[e];
+            x -= step * m1 / (sqrtf(v1) / bc2_sqrt + eps);
+            pp[e] = x; mm[e] = m1; vv[e] = v1;
+        }
+        ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+        if (wb) {
+            bf16x4 o = {(bf16)pp[0], (bf16)pp[1], (bf16)pp[2], (bf16)pp[3]};
+            ((bf16x4*)wb)[i] = o;
+        }
+    }
+}
+
+extern "C" int mmae_adamw_flat(float* p, const float* g, float* m, float* v, long n, long n_decay, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int step, float grad_scale, void* w_bf16,
+                               hipStream_t stream) {
+    MMAE_REQUIRE(p && g && m && v, MMAE_EINVAL, "adamw_flat: null pointer");
+    MMAE_REQUIRE(n >= 0 && n % 4 == 0 && n_decay >= 0 && n_decay <= n, MMAE_ESHAPE, "adamw_flat: n=%ld must be a multiple of 4, n_decay=%ld within it", n, n_decay);
+    MMAE_REQUIRE(step >= 1, MMAE_EINVAL, "adamw_flat: step counts from 1");
+    if (n == 0) return MMAE_OK;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    const long n4 = n / 4;
+    int blocks = (int)((n4 + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adamw_flat_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n4, n_decay, lr, beta1, beta2, eps,
+                       weight_decay, bc1, bc2s, grad_scale, (bf16*)w_bf16);
+    MMAE_CHECK_LAUNCH("adamw_flat");
+    return MMAE_OK;
+}
+
+#define SUMSQ_BLOCKS 1024
+__global__ void sumsq_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ part) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = ((const f32x4*)x)[i];
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0) for (long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) s += x[i] * x[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void sumsq_final_kernel(const float* __restrict__ part, int nparts, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += part[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+extern "C" int mmae_sumsq(const float* x, long n, float* out, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    MMAE_REQUIRE(x && out && workspace, MMAE_EINVAL, "sumsq: null pointer");
+    MMAE_REQUIRE(workspace_bytes >= SUMSQ_BLOCKS * sizeof(float), MMAE_EWORKSPACE, "sumsq: workspace must hold %d floats", SUMSQ_BLOCKS);
+    MMAE_REQUIRE(((uintptr_t)x % 16) == 0, MMAE_EINVAL, "sumsq: x must be 16-byte aligned");
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, stream, x, n, (float*)workspace);
+    MMAE_CHECK_LAUNCH("sumsq_partial");
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, SUMSQ_BLOCKS, out);
+    MMAE_CHECK_LAUNCH("sumsq_final");
+    return MMAE_OK;
+}
+
+// dst[r][c] = bf16(src[r][c]); dst_t[c][r] = bf16(src[r][c]); 64x64 tiles through LDS
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, int rows, int cols, bf16* __restrict__ dst,
+                                                             bf16* __restrict__ dst_t) {
+    __shared__ bf16 tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        bf16 v = (bf16)0.f;
+        if (r < rows && c < cols) {
+            v = (bf16)src[(long)r * cols + c];
+            if (dst) dst[(long)r * cols + c] = v;
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    if (dst_t) {
+        for (int i = ty; i < 64; i += 4) {
+            const int c = c0 + i, r = r0 + tx;
+            if (r < rows && c < cols) dst_t[(long)c * rows + r] = tile[tx][i];
+        }
+    }
+}
+extern "C" int mmae_cast_transpose(const float* src, int rows, int cols, void* dst_bf16, void* dst_t_bf16, hipStream_t stream) {
+    MMAE_REQUIRE(src && (dst_bf16 || dst_t_bf16) && rows > 0 && cols > 0, MMAE_EINVAL, "cast_transpose: bad argument");
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, stream, src, rows, cols,
+                       (bf16*)dst_bf16, (bf16*)dst_t_bf16);
+    MMAE_CHECK_LAUNCH("cast_transpose");
+    return MMAE_OK;
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, long n) {
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = ((const f32x4*)x)[i];
+        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        ((bf16x4*)y)[i] = o;
+    }
+    if (blockIdx.x == 0) for (long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) y[i] = (bf16)x[i];
+}
+extern "C" int mmae_cast_bf16(const float* x, void* y_bf16, long n, hipStream_t stream) {
+    MMAE_REQUIRE(x && y_bf16 && n >= 0, MMAE_EINVAL, "cast_bf16: bad argument");
+    if (n == 0) return MMAE_OK;
+    int blocks = (int)((n / 4 + 255) / 256); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, stream, x, (bf16*)y_bf16, n);
+    MMAE_CHECK_LAUNCH("cast_bf16");
+    return MMAE_OK;
+}

@@ -1,0 +1,331 @@
+// Token plumbing around the encoder and the decoders (gfx950): HBM-bound gather / scatter kernels that
+// replace the reference's cat / repeat / gather-with-expanded-int64-index sequences.
+#include "common.h"
+
+#define TOK_MAX_TASKS 8
+
+// ---------------------------------------------------------------------------------------------
+// pack the kept patches:  row (b*k + j) of A[B*k, Ktot] (bf16) =
+//   [ zeros | patch of token ids_keep[b,j] in (c, ph, pw) order at its domain's column block | zeros | one-hot(domain) | zeros ]
+// The trailing one-hot columns (at Kpatch + t) make the weight-gradient GEMM also produce the per-domain bias gradient.
+// ---------------------------------------------------------------------------------------------
+struct PackArgs {
+    const float* img[TOK_MAX_TASKS];
+    int chan[TOK_MAX_TASKS];
+    int koff[TOK_MAX_TASKS + 1];
+    int T, B, H, W, P, k, Ktot, ntok, nw;
+    const int* ids_keep;
+    bf16* out;
+};
+
+__global__ __launch_bounds__(128) void pack_patches_kernel(PackArgs a) {
+    const int row = blockIdx.x;
+    const int b = row / a.k;
+    const int id = a.ids_keep[row];
+    const int t = id / a.ntok, pos = id - t * a.ntok;
+    const int ph0 = (pos / a.nw) * a.P, pw0 = (pos % a.nw) * a.P;
+    const int pp = a.P * a.P;
+    const int Kpatch = a.koff[a.T];
+    bf16* orow = a.out + (long)row * a.Ktot;
+    for (int g = threadIdx.x; g < a.Ktot / 8; g += blockDim.x) {
+        const int kk = g * 8;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)0.f;
+        if (kk >= a.koff[t] && kk < a.koff[t + 1]) {
+            const int l = kk - a.koff[t];
+            const int c = l / pp, rem = l - c * pp, ph = rem / a.P, pw = rem - ph * a.P;
+            const float* src = a.img[t] + (((long)b * a.chan[t] + c) * a.H + ph0 + ph) * a.W + pw0 + pw;
+            const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+            o = (bf16x8){(bf16)v0[0], (bf16)v0[1], (bf16)v0[2], (bf16)v0[3], (bf16)v1[0], (bf16)v1[1], (bf16)v1[2], (bf16)v1[3]};
+        } else if (kk == Kpatch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)(e == t ? 1.f : 0.f);
+        }
+        *(bf16x8*)(orow + kk) = o;
+    }
+}
+
+extern "C" int mmae_pack_patches(const float* const* images_host, const int* channels_host, int T, int B, int H, int W, int P,
+                                 const int* ids_keep_i32, int k, void* out_bf16, int Ktot, hipStream_t stream) {
+    MMAE_REQUIRE(images_host && channels_host && ids_keep_i32 && out_bf16, MMAE_EINVAL, "pack_patches: null pointer");
+    MMAE_REQUIRE(T >= 1 && T <= TOK_MAX_TASKS, MMAE_ESHAPE, "pack_patches: T=%d", T);
+    MMAE_REQUIRE(P % 8 == 0 && H % P == 0 && W % P == 0 && W % 4 == 0, MMAE_ESHAPE, "pack_patches: patch %d must be a multiple of 8 and divide %dx%d", P, H, W);
+    if (B * k == 0) return MMAE_OK;
+    PackArgs a = {};
+    a.koff[0] = 0;
+    for (int t = 0; t < T; ++t) {
+        MMAE_REQUIRE(images_host[t], MMAE_EINVAL, "pack_patches: image %d is null", t);
+        a.img[t] = images_host[t]; a.chan[t] = channels_host[t];
+        a.koff[t + 1] = a.koff[t] + channels_host[t] * P * P;
+    }
+    MMAE_REQUIRE(Ktot % 64 == 0 && Ktot >= a.koff[T] + 8, MMAE_ESHAPE, "pack_patches: Ktot=%d must be a multiple of 64 and >= %d", Ktot, a.koff[T] + 8);
+    a.T = T; a.B = B; a.H = H; a.W = W; a.P = P; a.k = k; a.Ktot = Ktot; a.nw = W / P; a.ntok = (H / P) * (W / P);
+    a.ids_keep = ids_keep_i32; a.out = (bf16*)out_bf16;
+    hipLaunchKernelGGL(pack_patches_kernel, dim3(B * k), dim3(128), 0, stream, a);
+    MMAE_CHECK_LAUNCH("pack_patches");
+    return MMAE_OK;
+}
+
+// add_tab[t*ntok + pos][n] = pos_emb_t[n*ntok + pos] + bias_t[n]
+struct TabArgs { const float* pos[TOK_MAX_TASKS]; const float* bias[TOK_MAX_TASKS]; int T, ntok, dim; float* tab; };
+__global__ void build_token_table_kernel(TabArgs a) {
+    const long n_all = (long)a.T * a.ntok * a.dim;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % a.dim);
+        const int tp = (int)(i / a.dim);
+        const int t = tp / a.ntok, pos = tp - t * a.ntok;
+        a.tab[i] = a.pos[t][(long)n * a.ntok + pos] + (a.bias[t] ? a.bias[t][n] : 0.f);
+    }
+}
+extern "C" int mmae_build_token_table(const float* const* pos_emb_host, const float* const* bias_host, int T, int ntok, int dim,
+                                      float* add_tab, hipStream_t stream) {
+    MMAE_REQUIRE(pos_emb_host && bias_host && add_tab && T >= 1 && T <= TOK_MAX_TASKS, MMAE_EINVAL, "build_token_table: bad argument");
+    TabArgs a = {};
+    for (int t = 0; t < T; ++t) { a.pos[t] = pos_emb_host[t]; a.bias[t] = bias_host[t]; MMAE_REQUIRE(a.pos[t], MMAE_EINVAL, "build_token_table: null table"); }
+    a.T = T; a.ntok = ntok; a.dim = dim; a.tab = add_tab;
+    hipLaunchKernelGGL(build_token_table_kernel, dim3(512), dim3(256), 0, stream, a);
+    MMAE_CHECK_LAUNCH("build_token_table");
+    return MMAE_OK;
+}
+
+__global__ void append_global_kernel(const float* __restrict__ g, float* __restrict__ x, int B, int k, int G, int dim) {
+    const long n_all = (long)B * G * dim;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % dim);
+        const int bg = (int)(i / dim);
+        const int b = bg / G, gi = bg - b * G;
+        x[((long)b * (k + G) + k + gi) * dim + d] = g[(long)gi * dim + d];
+    }
+}
+extern "C" int mmae_append_global(const float* global_tokens, float* x, int B, int k, int G, int dim, hipStream_t stream) {
+    MMAE_REQUIRE(global_tokens && x, MMAE_EINVAL, "append_global: null pointer");
+    if (B * G * dim == 0) return MMAE_OK;
+    hipLaunchKernelGGL(append_global_kernel, dim3(256), dim3(256), 0, stream, global_tokens, x, B, k, G, dim);
+    MMAE_CHECK_LAUNCH("append_global");
+    return MMAE_OK;
+}
+
+// d_global[g,:] = sum_b dx[b,k+g,:]  and  rows_bf16[b*k + j,:] = bf16(dx[b,j,:])
+__global__ void embed_bwd_kernel(const float* __restrict__ dx, int B, int k, int G, int dim, float* __restrict__ d_global,
+                                 bf16* __restrict__ rows) {
+    const int seq = k + G;
+    const long n_rows4 = (long)B * k * (dim / 4);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (dim / 4));
+        const long bj = i / (dim / 4);
+        const int b = (int)(bj / k), j = (int)(bj - (long)b * k);
+        const f32x4 v = *(const f32x4*)(dx + ((long)b * seq + j) * dim + c * 4);
+        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *(bf16x4*)(rows + bj * dim + c * 4) = o;
+    }
+    // global-token gradient: one thread per (g, d), serial over the batch (B*G*dim is tiny)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)G * dim; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % dim), gi = (int)(i / dim);
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dx[((long)b * seq + k + gi) * dim + d];
+        d_global[i] = s;
+    }
+}
+extern "C" int mmae_embed_bwd_reduce(const float* dx, const int* ids_keep_i32, int B, int k, int G, int dim, int T, int ntok,
+                                     float* d_global, float* const* d_bias_host, void* dx_bf16_rows, hipStream_t stream) {
+    (void)ids_keep_i32; (void)T; (void)ntok; (void)d_bias_host;  // bias gradients come out of the weight-gradient GEMM
+    MMAE_REQUIRE(dx && d_global && dx_bf16_rows && dim % 4 == 0, MMAE_EINVAL, "embed_bwd_reduce: bad argument");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(1024), dim3(256), 0, stream, dx, B, k, G, dim, d_global, (bf16*)dx_bf16_rows);
+    MMAE_CHECK_LAUNCH("embed_bwd");
+    return MMAE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// decoder assembly
+// ---------------------------------------------------------------------------------------------
+struct AsmArgs {
+    const bf16* ctx; const float* mask_token; const float* emb; const int* ids_keep; const int* ids_restore;
+    int B, k, G, total, q_start, q_len, Dd;
+    float* queries; float* context;
+};
+// one block per output row (queries first, then context rows); Dd/4 <= blockDim
+__global__ __launch_bounds__(64) void decoder_assemble_fwd_kernel(AsmArgs a) {
+    const int rows_per_b = a.q_len + a.k + a.G;
+    const int b = blockIdx.x / rows_per_b, rr = blockIdx.x - b * rows_per_b;
+    const int seq = a.k + a.G;
+    for (int c = threadIdx.x; c < a.Dd / 4; c += blockDim.x) {
+        f32x4 v;
+        if (rr < a.q_len) {
+            const int pos = a.q_start + rr;
+            const int r = a.ids_restore[(long)b * a.total + pos];
+            if (r < a.k) {
+                const bf16x4 s = *(const bf16x4*)(a.ctx + ((long)b * seq + r) * a.Dd + c * 4);
+                v = (f32x4){(float)s[0], (float)s[1], (float)s[2], (float)s[3]};
+            } else {
+                v = ((const f32x4*)a.mask_token)[c];
+            }
+            v += ((const f32x4*)(a.emb + (long)pos * a.Dd))[c];
+            ((f32x4*)(a.queries + ((long)b * a.q_len + rr) * a.Dd))[c] = v;
+        } else {
+            const int j = rr - a.q_len;
+            const bf16x4 s = *(const bf16x4*)(a.ctx + ((long)b * seq + j) * a.Dd + c * 4);
+            v = (f32x4){(float)s[0], (float)s[1], (float)s[2], (float)s[3]};
+            if (j < a.k) {
+                // gather(full, ids_keep): full[pos] = (ids_restore[pos] < k ? ctx[ids_restore[pos]] : mask_token) + emb[pos]
+                const int pos = a.ids_keep[(long)b * a.k + j];
+                const int r = a.ids_restore[(long)b * a.total + pos];
+                if (r != j) {
+                    if (r < a.k) {
+                        const bf16x4 s2 = *(const bf16x4*)(a.ctx + ((long)b * seq + r) * a.Dd + c * 4);
+                        v = (f32x4){(float)s2[0], (float)s2[1], (float)s2[2], (float)s2[3]};
+                    } else {
+                        v = ((const f32x4*)a.mask_token)[c];
+                    }
+                }
+                v += ((const f32x4*)(a.emb + (long)pos * a.Dd))[c];
+            }
+            ((f32x4*)(a.context + ((long)b * seq + j) * a.Dd))[c] = v;
+        }
+    }
+}
+
+extern "C" int mmae_decoder_assemble_fwd(const void* ctx_bf16, const float* mask_token, const float* emb, const int* ids_keep_i32,
+                                         const int* ids_restore_i32, int B, int k, int G, int total, int q_start, int q_len,
+                                         int Dd, float* queries, float* context, hipStream_t stream) {
+    MMAE_REQUIRE(ctx_bf16 && mask_token && emb && ids_keep_i32 && ids_restore_i32 && queries && context, MMAE_EINVAL,
+                 "decoder_assemble_fwd: null pointer");
+    MMAE_REQUIRE(Dd % 4 == 0 && q_start >= 0 && q_start + q_len <= total && k <= total, MMAE_ESHAPE, "decoder_assemble_fwd: bad shape");
+    if (B == 0) return MMAE_OK;
+    AsmArgs a = {(const bf16*)ctx_bf16, mask_token, emb, ids_keep_i32, ids_restore_i32, B, k, G, total, q_start, q_len, Dd, queries, context};
+    hipLaunchKernelGGL(decoder_assemble_fwd_kernel, dim3(B * (q_len + k + G)), dim3(64), 0, stream, a);
+    MMAE_CHECK_LAUNCH("decoder_assemble_fwd");
+    return MMAE_OK;
+}
+
+// backward: d_ctx (gather form, no atomics) and per-sample partial sums for mask_token / task embeddings
+struct AsmBwdArgs {
+    const float* dq; const float* dc; const int* ids_keep; const int* ids_restore;
+    int B, k, G, total, q_start, q_len, Dd, T, ntok;
+    bf16* d_ctx; float* part;  // part[b][T+1][Dd]
+};
+__global__ __launch_bounds__(256) void decoder_assemble_bwd_kernel(AsmBwdArgs a) {
+    const int b = blockIdx.x;
+    const int seq = a.k + a.G;
+    const int nv = a.Dd / 4;
+    // d_ctx rows
+    for (int i = threadIdx.x; i < seq * nv; i += blockDim.x) {
+        const int j = i / nv, c = i - j * nv;
+        f32x4 v = ((const f32x4*)(a.dc + ((long)b * seq + j) * a.Dd))[c];
+        if (j < a.k) {
+            const int pos = a.ids_keep[(long)b * a.k + j];
+            if (pos >= a.q_start && pos < a.q_start + a.q_len)
+                v += ((const f32x4*)(a.dq + ((long)b * a.q_len + pos - a.q_start) * a.Dd))[c];
+        }
+        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *(bf16x4*)(a.d_ctx + ((long)b * seq + j) * a.Dd + c * 4) = o;
+    }
+    // partial sums over positions: slot t < T collects d_emb of task t, slot T the mask token.
+    // threads are laid out as (column group c, position lane pl); each walks positions pl, pl+PL, ...
+    __shared__ float red[256 * 4];
+    const int PL = blockDim.x / nv;  // position lanes (Dd=256 -> nv=64 -> 4)
+    const int c = threadIdx.x % nv, pl = threadIdx.x / nv;
+    for (int slot = 0; slot <= a.T; ++slot) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (pl < PL) {
+            const int p0 = slot < a.T ? slot * a.ntok : 0;
+            const int p1 = slot < a.T ? p0 + a.ntok : a.total;
+            for (int pos = p0 + pl; pos < p1; pos += PL) {
+                const int r = a.ids_restore[(long)b * a.total + pos];
+                const bool in_q = pos >= a.q_start && pos < a.q_start + a.q_len;
+                if (slot < a.T) {
+                    if (in_q) s += ((const f32x4*)(a.dq + ((long)b * a.q_len + pos - a.q_start) * a.Dd))[c];
+                    if (r < a.k) s += ((const f32x4*)(a.dc + ((long)b * seq + r) * a.Dd))[c];
+                } else if (in_q && r >= a.k) {
+                    s += ((const f32x4*)(a.dq + ((long)b * a.q_len + pos - a.q_start) * a.Dd))[c];
+                }
+            }
+        }
+        __syncthreads();
+        *(f32x4*)&red[threadIdx.x * 4] = s;
+        __syncthreads();
+        if (pl == 0) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < PL; ++q) t += *(f32x4*)&red[(q * nv + c) * 4];
+            *(f32x4*)(a.part + ((long)b * (a.T + 1) + slot) * a.Dd + c * 4) = t;
+        }
+    }
+}
+struct AsmRedArgs { const float* part; int B, T, Dd; float* d_mask_token; float* d_task[TOK_MAX_TASKS]; int accumulate; };
+__global__ void decoder_assemble_reduce_kernel(AsmRedArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (a.T + 1) * a.Dd) return;
+    const int slot = i / a.Dd, d = i - slot * a.Dd;
+    float s = 0.f;
+    for (int b = 0; b < a.B; ++b) s += a.part[((long)b * (a.T + 1) + slot) * a.Dd + d];
+    float* dst = slot < a.T ? a.d_task[slot] : a.d_mask_token;
+    if (dst) dst[d] = a.accumulate ? dst[d] + s : s;
+}
+
+extern "C" size_t mmae_decoder_assemble_bwd_workspace_bytes(int B, int T, int Dd) { return (size_t)B * (T + 1) * Dd * sizeof(float); }
+
+extern "C" int mmae_decoder_assemble_bwd(const float* d_queries, const float* d_context, const int* ids_keep_i32,
+                                         const int* ids_restore_i32, int B, int k, int G, int T, int ntok, int q_start, int q_len,
+                                         int Dd, void* d_ctx_bf16, float* d_mask_token, float* const* d_task_emb_host,
+                                         void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    MMAE_REQUIRE(d_queries && d_context && ids_keep_i32 && ids_restore_i32 && d_ctx_bf16 && d_mask_token && d_task_emb_host && workspace,
+                 MMAE_EINVAL, "decoder_assemble_bwd: null pointer");
+    MMAE_REQUIRE(T >= 1 && T <= TOK_MAX_TASKS && Dd % 4 == 0 && Dd / 4 <= 256, MMAE_ESHAPE, "decoder_assemble_bwd: bad shape (T=%d Dd=%d)", T, Dd);
+    MMAE_REQUIRE(workspace_bytes >= mmae_decoder_assemble_bwd_workspace_bytes(B, T, Dd), MMAE_EWORKSPACE, "decoder_assemble_bwd: workspace too small");
+    if (B == 0) return MMAE_OK;
+    AsmBwdArgs a = {d_queries, d_context, ids_keep_i32, ids_restore_i32, B, k, G, T * ntok, q_start, q_len, Dd, T, ntok,
+                    (bf16*)d_ctx_bf16, (float*)workspace};
+    hipLaunchKernelGGL(decoder_assemble_bwd_kernel, dim3(B), dim3(256), 0, stream, a);
+    MMAE_CHECK_LAUNCH("decoder_assemble_bwd");
+    AsmRedArgs r = {};
+    r.part = (const float*)workspace; r.B = B; r.T = T; r.Dd = Dd; r.d_mask_token = d_mask_token; r.accumulate = 0;
+    for (int t = 0; t < T; ++t) r.d_task[t] = d_task_emb_host[t];
+    hipLaunchKernelGGL(decoder_assemble_reduce_kernel, dim3(((T + 1) * Dd + 255) / 256), dim3(256), 0, stream, r);
+    MMAE_CHECK_LAUNCH("decoder_assemble_reduce");
+    return MMAE_OK;
+}
+
+// emb[t*ntok + pos][d] = task_emb_t[d] + pos_emb[d*ntok + pos]
+struct EmbArgs { const float* task[TOK_MAX_TASKS]; const float* pos; int T, ntok, Dd; float* emb; };
+__global__ void build_decoder_emb_kernel(EmbArgs a) {
+    const long n_all = (long)a.T * a.ntok * a.Dd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % a.Dd);
+        const int tp = (int)(i / a.Dd);
+        const int t = tp / a.ntok, pos = tp - t * a.ntok;
+        a.emb[i] = (a.task[t] ? a.task[t][d] : 0.f) + a.pos[(long)d * a.ntok + pos];
+    }
+}
+extern "C" int mmae_build_decoder_emb(const float* const* task_emb_host, const float* pos_emb, int T, int ntok, int Dd, float* emb,
+                                      hipStream_t stream) {
+    MMAE_REQUIRE(task_emb_host && pos_emb && emb && T >= 1 && T <= TOK_MAX_TASKS, MMAE_EINVAL, "build_decoder_emb: bad argument");
+    EmbArgs a = {};
+    for (int t = 0; t < T; ++t) a.task[t] = task_emb_host[t];
+    a.pos = pos_emb; a.T = T; a.ntok = ntok; a.Dd = Dd; a.emb = emb;
+    hipLaunchKernelGGL(build_decoder_emb_kernel, dim3(256), dim3(256), 0, stream, a);
+    MMAE_CHECK_LAUNCH("build_decoder_emb");
+    return MMAE_OK;
+}
+
+// image bf16 [B,C,NH*P,NW*P] -> rows bf16 [B*NH*NW, C*P*P] ((c, ph, pw) inner order)
+__global__ void patchify_bf16_kernel(const bf16* __restrict__ img, int B, int C, int NH, int NW, int P, bf16* __restrict__ rows) {
+    const int g_per_row = C * P * P / 4;
+    const long n_all = (long)B * NH * NW * g_per_row;
+    const long H = (long)NH * P, W = (long)NW * P;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % g_per_row);
+        const long tok = i / g_per_row;
+        const int b = (int)(tok / (NH * NW));
+        const int t = (int)(tok - (long)b * NH * NW);
+        const int nh = t / NW, nw = t - nh * NW;
+        const int n = g * 4, c = n / (P * P), rem = n - c * P * P, ph = rem / P, pw = rem - ph * P;
+        *(bf16x4*)(rows + tok * (C * P * P) + n) = *(const bf16x4*)(img + (((long)b * C + c) * H + nh * P + ph) * W + nw * P + pw);
+    }
+}
+extern "C" int mmae_patchify_bf16(const void* image, int B, int C, int NH, int NW, int P, void* rows, hipStream_t stream) {
+    MMAE_REQUIRE(image && rows && P % 4 == 0, MMAE_EINVAL, "patchify: bad argument");
+    if (B == 0) return MMAE_OK;
+    hipLaunchKernelGGL(patchify_bf16_kernel, dim3(2048), dim3(256), 0, stream, (const bf16*)image, B, C, NH, NW, P, (bf16*)rows);
+    MMAE_CHECK_LAUNCH("patchify");
+    return MMAE_OK;
+}

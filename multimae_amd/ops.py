@@ -1,0 +1,350 @@
+"""Tensor-level wrappers of the C ABI (include/mmae.h): argument checks, output allocation, stream plumbing.
+
+Everything here runs the HIP kernels; there is no eager/CPU fallback.  torch is used for device memory and
+for the current stream only."""
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+EPI_BF16, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_F32 = 0, 1, 2, 3, 4
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _L():
+    return _lib.load()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _req(t: torch.Tensor, dtype, name: str, contiguous=True):
+    if not t.is_cuda:
+        raise _lib.MmaeError(f"{name}: expected a tensor on the GPU (the HIP kernels are the only implementation)")
+    if t.dtype != dtype:
+        raise _lib.MmaeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise _lib.MmaeError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+def _rows2d(t: torch.Tensor, name: str):
+    """(pointer tensor, rows, cols, row stride) of a 2-D view whose last dim is dense."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise _lib.MmaeError(f"{name}: expected a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+_WS = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per device; every kernel that uses it runs on the current stream."""
+    key = torch.device(device).index
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# --------------------------------------------------------------------------------------------- GEMMs
+def gemm_nt(epi: int, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+            aux: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """out[M,N] = a[M,K] @ w[N,K]^T with epilogue `epi`. Returns out (and the activation for EPI_GELU)."""
+    _req(a, BF16, "gemm_nt a", contiguous=False)
+    _req(w, BF16, "gemm_nt w", contiguous=False)
+    M, K, lda = _rows2d(a, "gemm_nt a")
+    N, K2, ldw = _rows2d(w, "gemm_nt w")
+    if K != K2:
+        raise _lib.MmaeError(f"gemm_nt: inner dims differ ({K} vs {K2})")
+    out_dtype = F32 if epi in (EPI_RESID, EPI_F32) else BF16
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    else:
+        _req(out, out_dtype, "gemm_nt out", contiguous=False)
+    _, _, ldo = _rows2d(out, "gemm_nt out")
+    out2 = torch.empty((M, N), dtype=BF16, device=a.device) if epi == EPI_GELU else None
+    ldaux = 0
+    if aux is not None:
+        _req(aux, F32 if epi == EPI_RESID else BF16, "gemm_nt aux", contiguous=False)
+        _, _, ldaux = _rows2d(aux, "gemm_nt aux")
+    if bias is not None:
+        _req(bias, F32, "gemm_nt bias")
+    _lib.check(_L().mmae_gemm_nt(epi, _ptr(a), lda, _ptr(w), ldw, M, N, K, _ptr(bias), _ptr(out), ldo, _ptr(out2),
+                                 _ptr(aux), ldaux, _stream()), "gemm_nt")
+    return (out, out2) if epi == EPI_GELU else out
+
+
+def gemm_tn(x: torch.Tensor, y: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """out[N,K] (f32) (+)= x[M,N]^T @ y[M,K]."""
+    _req(x, BF16, "gemm_tn x", contiguous=False)
+    _req(y, BF16, "gemm_tn y", contiguous=False)
+    M, N, ldx = _rows2d(x, "gemm_tn x")
+    M2, K, ldy = _rows2d(y, "gemm_tn y")
+    if M != M2:
+        raise _lib.MmaeError(f"gemm_tn: row counts differ ({M} vs {M2})")
+    if out is None:
+        out = torch.empty((N, K), dtype=F32, device=x.device)
+        accumulate = False
+    else:
+        _req(out, F32, "gemm_tn out")
+    nbytes = _L().mmae_gemm_tn_workspace_bytes(M, N, K)
+    ws = workspace(nbytes, x.device)
+    _lib.check(_L().mmae_gemm_tn(_ptr(x), ldx, _ptr(y), ldy, M, N, K, _ptr(out), int(accumulate), _ptr(ws), ws.numel(),
+                                 _stream()), "gemm_tn")
+    return out
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    _req(x, BF16, "colsum x", contiguous=False)
+    M, N, ldx = _rows2d(x, "colsum x")
+    if out is None:
+        out = torch.empty((N,), dtype=F32, device=x.device)
+        accumulate = False
+    ws = workspace(_L().mmae_colsum_workspace_bytes(M, N), x.device)
+    _lib.check(_L().mmae_colsum_bf16(_ptr(x), ldx, M, N, _ptr(out), int(accumulate), _ptr(ws), ws.numel(), _stream()), "colsum")
+    return out
+
+
+# --------------------------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-6):
+    _req(x, F32, "layernorm x"); _req(gamma, F32, "layernorm gamma"); _req(beta, F32, "layernorm beta")
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    mean = torch.empty((rows,), dtype=F32, device=x.device)
+    rstd = torch.empty((rows,), dtype=F32, device=x.device)
+    _lib.check(_L().mmae_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), rows, dim, eps,
+                                       _stream()), "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
+                  dres: Optional[torch.Tensor] = None, want_bf16: bool = False):
+    """Returns (dx f32 [= dres + LN'(dy)], dx bf16 or None, dgamma, dbeta)."""
+    _req(dy, BF16, "layernorm_bwd dy"); _req(x, F32, "layernorm_bwd x")
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    if dres is not None:
+        _req(dres, F32, "layernorm_bwd dres")
+    dx = torch.empty(x.shape, dtype=F32, device=x.device)
+    dxb = torch.empty(x.shape, dtype=BF16, device=x.device) if want_bf16 else None
+    dgamma = torch.empty((dim,), dtype=F32, device=x.device)
+    dbeta = torch.empty((dim,), dtype=F32, device=x.device)
+    ws = workspace(_L().mmae_layernorm_bwd_workspace_bytes(rows, dim), x.device)
+    _lib.check(_L().mmae_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(dxb),
+                                       _ptr(dgamma), _ptr(dbeta), 0, rows, dim, _ptr(ws), ws.numel(), _stream()), "layernorm_bwd")
+    return dx, dxb, dgamma, dbeta
+
+
+# --------------------------------------------------------------------------------------------- attention
+def _head_view(t: torch.Tensor, name: str):
+    """t is [B, L, H*d-ish] viewed through a row stride: return (ld) for a tensor whose rows are (b*L + i)."""
+    if t.stride(-1) != 1:
+        raise _lib.MmaeError(f"{name}: inner stride must be 1")
+    return t.stride(-2)
+
+
+def attn_fwd(q, k, v, B, H, q_len, kv_len, head_dim, scale):
+    """q: [B*q_len, >=H*d] view, k/v: [B*kv_len, ...] views (row-strided slices of packed projections).
+    Returns (o [B*q_len, H*d] bf16, lse [B,H,q_len] f32)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _req(t, BF16, f"attn_fwd {n}", contiguous=False)
+    o = torch.empty((B * q_len, H * head_dim), dtype=BF16, device=q.device)
+    lse = torch.empty((B, H, q_len), dtype=F32, device=q.device)
+    _lib.check(_L().mmae_attn_fwd(_ptr(q), _head_view(q, "q"), _ptr(k), _head_view(k, "k"), _ptr(v), _head_view(v, "v"),
+                                  _ptr(o), o.stride(0), _ptr(lse), B, H, q_len, kv_len, head_dim, float(scale), _stream()),
+               "attn_fwd")
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, q_len, kv_len, head_dim, scale):
+    """Gradients are written into the (row-strided) views dq / dk / dv."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (d_o, "dO"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        _req(t, BF16, f"attn_bwd {n}", contiguous=False)
+    _req(lse, F32, "attn_bwd lse")
+    _lib.check(_L().mmae_attn_bwd(_ptr(q), _head_view(q, "q"), _ptr(k), _head_view(k, "k"), _ptr(v), _head_view(v, "v"),
+                                  _ptr(o), _head_view(o, "o"), _ptr(d_o), _head_view(d_o, "dO"), _ptr(lse),
+                                  _ptr(dq), _head_view(dq, "dq"), _ptr(dk), _head_view(dk, "dk"), _ptr(dv), _head_view(dv, "dv"),
+                                  B, H, q_len, kv_len, head_dim, float(scale), _stream()), "attn_bwd")
+
+
+# --------------------------------------------------------------------------------------------- masking
+def mask_generate(task_dist: torch.Tensor, noise: torch.Tensor, noise_all: torch.Tensor, tokens_per_task: Sequence[int],
+                  num_encoded: int):
+    """Returns (mask [B,total] i64, ids_keep [B,k] i64, ids_restore [B,total] i64, ids_keep i32, ids_restore i32)."""
+    _req(task_dist, F32, "mask task_dist"); _req(noise, F32, "mask noise"); _req(noise_all, F32, "mask noise_all")
+    B, T = task_dist.shape
+    total = int(sum(tokens_per_task))
+    if noise.shape != (B, total) or noise_all.shape != (B, total) or T != len(tokens_per_task):
+        raise _lib.MmaeError("mask_generate: noise tensors must be [B, sum(tokens_per_task)]")
+    dev = task_dist.device
+    ids_keep = torch.empty((B, num_encoded), dtype=torch.int64, device=dev)
+    ids_restore = torch.empty((B, total), dtype=torch.int64, device=dev)
+    mask = torch.empty((B, total), dtype=torch.int64, device=dev)
+    keep32 = torch.empty((B, num_encoded), dtype=torch.int32, device=dev)
+    restore32 = torch.empty((B, total), dtype=torch.int32, device=dev)
+    toks = (C.c_int * T)(*[int(n) for n in tokens_per_task])
+    _lib.check(_L().mmae_mask_generate(_ptr(task_dist), _ptr(noise), _ptr(noise_all), toks, T, B, int(num_encoded),
+                                       _ptr(ids_keep), _ptr(ids_restore), _ptr(mask), _ptr(keep32), _ptr(restore32), _stream()),
+               "mask_generate")
+    return mask, ids_keep, ids_restore, keep32, restore32
+
+
+# --------------------------------------------------------------------------------------------- token plumbing
+def _ptr_array(ts: Sequence[Optional[torch.Tensor]]):
+    return (C.c_void_p * len(ts))(*[0 if t is None else t.data_ptr() for t in ts])
+
+
+def pack_patches(images: Sequence[torch.Tensor], patch: int, ids_keep32: torch.Tensor, ktot: int):
+    B, _, H, W = images[0].shape
+    for im in images:
+        _req(im, F32, "pack_patches image")
+    k = ids_keep32.shape[1]
+    out = torch.empty((B * k, ktot), dtype=BF16, device=images[0].device)
+    chans = (C.c_int * len(images))(*[int(im.shape[1]) for im in images])
+    _lib.check(_L().mmae_pack_patches(_ptr_array(images), chans, len(images), B, H, W, patch, _ptr(ids_keep32), k, _ptr(out),
+                                      ktot, _stream()), "pack_patches")
+    return out
+
+
+def build_token_table(pos_embs: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], ntok: int, dim: int):
+    tab = torch.empty((len(pos_embs) * ntok, dim), dtype=F32, device=pos_embs[0].device)
+    _lib.check(_L().mmae_build_token_table(_ptr_array(pos_embs), _ptr_array(biases), len(pos_embs), ntok, dim, _ptr(tab),
+                                           _stream()), "build_token_table")
+    return tab
+
+
+def patch_embed_gemm(a: torch.Tensor, wcat: torch.Tensor, add_idx: torch.Tensor, add_tab: torch.Tensor, seg_in: int,
+                     seg_out: int, out: torch.Tensor):
+    M, K = a.shape
+    N = wcat.shape[0]
+    _lib.check(_L().mmae_patch_embed_gemm(_ptr(a), _ptr(wcat), M, N, K, _ptr(add_idx), _ptr(add_tab), seg_in, seg_out,
+                                          _ptr(out), out.shape[-1], _stream()), "patch_embed_gemm")
+    return out
+
+
+def append_global(global_tokens: torch.Tensor, x: torch.Tensor, k: int):
+    B, seq, dim = x.shape
+    _lib.check(_L().mmae_append_global(_ptr(global_tokens), _ptr(x), B, k, seq - k, dim, _stream()), "append_global")
+
+
+def embed_bwd_reduce(dx: torch.Tensor, k: int):
+    """dx f32 [B, k+G, D] -> (d_global [1,G,D] f32, rows bf16 [B*k, D])."""
+    _req(dx, F32, "embed_bwd dx")
+    B, seq, dim = dx.shape
+    G = seq - k
+    d_global = torch.empty((1, G, dim), dtype=F32, device=dx.device)
+    rows = torch.empty((B * k, dim), dtype=BF16, device=dx.device)
+    _lib.check(_L().mmae_embed_bwd_reduce(_ptr(dx), None, B, k, G, dim, 0, 0, _ptr(d_global), None, _ptr(rows), _stream()),
+               "embed_bwd_reduce")
+    return d_global, rows
+
+
+def build_decoder_emb(task_embs: Sequence[Optional[torch.Tensor]], pos_emb: torch.Tensor, ntok: int, dd: int):
+    emb = torch.empty((len(task_embs) * ntok, dd), dtype=F32, device=pos_emb.device)
+    _lib.check(_L().mmae_build_decoder_emb(_ptr_array(task_embs), _ptr(pos_emb), len(task_embs), ntok, dd, _ptr(emb), _stream()),
+               "build_decoder_emb")
+    return emb
+
+
+def decoder_assemble_fwd(ctx, mask_token, emb, keep32, restore32, k, G, q_start, q_len):
+    _req(ctx, BF16, "decoder_assemble ctx")
+    B, seq, dd = ctx.shape
+    total = restore32.shape[1]
+    queries = torch.empty((B, q_len, dd), dtype=F32, device=ctx.device)
+    context = torch.empty((B, seq, dd), dtype=F32, device=ctx.device)
+    _lib.check(_L().mmae_decoder_assemble_fwd(_ptr(ctx), _ptr(mask_token), _ptr(emb), _ptr(keep32), _ptr(restore32), B, k, G,
+                                              total, q_start, q_len, dd, _ptr(queries), _ptr(context), _stream()),
+               "decoder_assemble_fwd")
+    return queries, context
+
+
+def decoder_assemble_bwd(d_queries, d_context, keep32, restore32, k, G, T, ntok, q_start, q_len):
+    _req(d_queries, F32, "decoder_assemble_bwd d_queries"); _req(d_context, F32, "decoder_assemble_bwd d_context")
+    B, seq, dd = d_context.shape
+    dev = d_context.device
+    d_ctx = torch.empty((B, seq, dd), dtype=BF16, device=dev)
+    d_mask = torch.empty((1, 1, dd), dtype=F32, device=dev)
+    d_task = [torch.empty((1, 1, dd), dtype=F32, device=dev) for _ in range(T)]
+    ws = workspace(_L().mmae_decoder_assemble_bwd_workspace_bytes(B, T, dd), dev)
+    _lib.check(_L().mmae_decoder_assemble_bwd(_ptr(d_queries), _ptr(d_context), _ptr(keep32), _ptr(restore32), B, k, G, T, ntok,
+                                              q_start, q_len, dd, _ptr(d_ctx), _ptr(d_mask), _ptr_array(d_task), _ptr(ws),
+                                              ws.numel(), _stream()), "decoder_assemble_bwd")
+    return d_ctx, d_mask, d_task
+
+
+def unpatchify_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, C_: int, P: int, NH: int, NW: int):
+    M, K, lda = _rows2d(a, "unpatchify a")
+    N = w.shape[0]
+    img = torch.empty((B, C_, NH * P, NW * P), dtype=BF16, device=a.device)
+    _lib.check(_L().mmae_unpatchify_gemm(_ptr(a), lda, _ptr(w), M, N, K, _ptr(bias), _ptr(img), C_, P, NH, NW, _stream()),
+               "unpatchify_gemm")
+    return img
+
+
+def patchify_bf16(img: torch.Tensor, P: int):
+    _req(img, BF16, "patchify image")
+    B, C_, H, W = img.shape
+    rows = torch.empty((B * (H // P) * (W // P), C_ * P * P), dtype=BF16, device=img.device)
+    _lib.check(_L().mmae_patchify_bf16(_ptr(img), B, C_, H // P, W // P, P, _ptr(rows), _stream()), "patchify")
+    return rows
+
+
+# --------------------------------------------------------------------------------------------- losses
+def masked_loss(kind: int, norm_pix: bool, pred: torch.Tensor, target: torch.Tensor, mask: Optional[torch.Tensor], patch: int,
+                want_grad: bool = True):
+    """Returns (loss f32 scalar tensor, d_pred or None)."""
+    if pred.dtype not in (BF16, F32):
+        raise _lib.MmaeError(f"masked_loss: pred dtype {pred.dtype}")
+    _req(pred, pred.dtype, "masked_loss pred"); _req(target, F32, "masked_loss target")
+    if mask is not None:
+        _req(mask, torch.int64, "masked_loss mask")
+    B, C_, H, W = pred.shape
+    loss = torch.empty((), dtype=F32, device=pred.device)
+    d_pred = torch.empty_like(pred) if want_grad else None
+    ws = workspace(_L().mmae_masked_loss_workspace_bytes(B, C_, H, W, patch), pred.device)
+    _lib.check(_L().mmae_masked_loss(kind, int(norm_pix), _ptr(pred), int(pred.dtype == BF16), _ptr(target), _ptr(mask), B, C_, H,
+                                     W, patch, _ptr(loss), _ptr(d_pred), _ptr(ws), ws.numel(), _stream()), "masked_loss")
+    return loss, d_pred
+
+
+# --------------------------------------------------------------------------------------------- optimiser
+def adamw_flat(p, g, m, v, n_decay, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, w_bf16=None):
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _req(t, F32, f"adamw {n}")
+    _lib.check(_L().mmae_adamw_flat(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(n_decay), lr, beta1, beta2, eps,
+                                    weight_decay, int(step), float(grad_scale), _ptr(w_bf16), _stream()), "adamw_flat")
+
+
+def sumsq(x: torch.Tensor, out: Optional[torch.Tensor] = None):
+    _req(x, F32, "sumsq x")
+    if out is None:
+        out = torch.empty((), dtype=F32, device=x.device)
+    ws = workspace(4096, x.device)
+    _lib.check(_L().mmae_sumsq(_ptr(x), x.numel(), _ptr(out), _ptr(ws), ws.numel(), _stream()), "sumsq")
+    return out
+
+
+def cast_transpose(src: torch.Tensor, want: bool = True, want_t: bool = True):
+    _req(src, F32, "cast_transpose src")
+    rows, cols = src.shape
+    d = torch.empty((rows, cols), dtype=BF16, device=src.device) if want else None
+    dt = torch.empty((cols, rows), dtype=BF16, device=src.device) if want_t else None
+    _lib.check(_L().mmae_cast_transpose(_ptr(src), rows, cols, _ptr(d), _ptr(dt), _stream()), "cast_transpose")
+    return d, dt
+
+
+def cast_bf16(x: torch.Tensor):
+    _req(x, F32, "cast_bf16 x")
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    _lib.check(_L().mmae_cast_bf16(_ptr(x), _ptr(y), x.numel(), _stream()), "cast_bf16")
+    return y
