@@ -1,0 +1,277 @@
+"""Autograd functions that chain the HIP kernels into the pieces of the MultiMAE step.
+
+Precision plan (the reference's AMP semantics with bf16 as the low-precision type): parameters, the residual
+stream, LayerNorm statistics, softmax and the losses are fp32; every matrix product takes bf16 operands and
+accumulates in fp32.  Each function saves exactly what its backward kernels read."""
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+
+# ---------------------------------------------------------------------------------------------
+# bf16 copies of the fp32 master weights ([out,in] for the forward / dW, [in,out] for dA)
+# ---------------------------------------------------------------------------------------------
+_WEIGHT_EPOCH = 0
+_WEIGHT_CACHE: Dict[int, tuple] = {}
+
+
+def bump_weight_epoch():
+    """Called by optimisers that update parameters through raw pointers (no autograd version bump)."""
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+
+
+def bf16_weights(w: torch.Tensor):
+    """(w as bf16 [N,K], w^T as bf16 [K,N]) for a 2-D fp32 parameter, cached until the parameter changes."""
+    key = id(w)
+    ent = _WEIGHT_CACHE.get(key)
+    ver = (w._version, _WEIGHT_EPOCH, w.data_ptr())
+    if ent is not None and ent[0] == ver and ent[1] is w:
+        return ent[2], ent[3]
+    wb, wt = ops.cast_transpose(w.detach().reshape(w.shape[0], -1))
+    _WEIGHT_CACHE[key] = (ver, w, wb, wt)
+    return wb, wt
+
+
+def clear_weight_cache():
+    _WEIGHT_CACHE.clear()
+
+
+def _bf16(g: torch.Tensor) -> torch.Tensor:
+    return g if g.dtype == torch.bfloat16 else ops.cast_bf16(g.contiguous())
+
+
+def _lin_grads(dy_b: torch.Tensor, x_b: torch.Tensor):
+    """(dW [N,K] f32, db [N] f32) of y = x W^T + b from bf16 dy [M,N] and x [M,K]."""
+    return ops.gemm_tn(dy_b, x_b), ops.colsum(dy_b)
+
+
+# ---------------------------------------------------------------------------------------------
+# pieces shared by the encoder block, the decoder blocks and the decoder head
+# ---------------------------------------------------------------------------------------------
+def _mlp_fwd(x, n_w, n_b, fc1_w, fc1_b, fc2_w, fc2_b):
+    """x f32 [M,D] -> x + fc2(gelu(fc1(LN(x)))) and the tensors the backward needs."""
+    ln, mean, rstd = ops.layernorm_fwd(x, n_w, n_b)
+    w1, w1t = bf16_weights(fc1_w)
+    w2, w2t = bf16_weights(fc2_w)
+    h, act = ops.gemm_nt(ops.EPI_GELU, ln, w1, fc1_b)
+    y = ops.gemm_nt(ops.EPI_RESID, act, w2, fc2_b, aux=x)
+    return y, (x, ln, mean, rstd, h, act, w1t, w2t, n_w)
+
+
+def _mlp_bwd(g, saved):
+    """g f32 [M,D] (gradient of the block output) -> (dx f32, [dn_w, dn_b, dfc1_w, dfc1_b, dfc2_w, dfc2_b])."""
+    x, ln, mean, rstd, h, act, w1t, w2t, n_w = saved
+    gb = _bf16(g)
+    dh = ops.gemm_nt(ops.EPI_DGELU, gb, w2t, None, aux=h)
+    dw2, db2 = _lin_grads(gb, act)
+    dln = ops.gemm_nt(ops.EPI_BF16, dh, w1t, None)
+    dw1, db1 = _lin_grads(dh, ln)
+    dx, _, dnw, dnb = ops.layernorm_bwd(dln, x, n_w, mean, rstd, dres=g)
+    return dx, [dnw, dnb, dw1, db1, dw2, db2]
+
+
+def _self_attn_fwd(x, B, N, heads, n_w, n_b, qkv_w, qkv_b, proj_w, proj_b):
+    D = x.shape[-1]
+    d = D // heads
+    ln, mean, rstd = ops.layernorm_fwd(x, n_w, n_b)
+    wq, wqt = bf16_weights(qkv_w)
+    wp, wpt = bf16_weights(proj_w)
+    qkv = ops.gemm_nt(ops.EPI_BF16, ln, wq, qkv_b)
+    o, lse = ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, heads, N, N, d, d ** -0.5)
+    y = ops.gemm_nt(ops.EPI_RESID, o, wp, proj_b, aux=x)
+    return y, (x, ln, mean, rstd, qkv, o, lse, wqt, wpt, n_w, B, N, heads)
+
+
+def _self_attn_bwd(g, saved):
+    x, ln, mean, rstd, qkv, o, lse, wqt, wpt, n_w, B, N, heads = saved
+    D = x.shape[-1]
+    d = D // heads
+    gb = _bf16(g)
+    d_o = ops.gemm_nt(ops.EPI_BF16, gb, wpt, None)
+    dwp, dbp = _lin_grads(gb, o)
+    dqkv = torch.empty_like(qkv)
+    ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, d_o, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                 B, heads, N, N, d, d ** -0.5)
+    dln = ops.gemm_nt(ops.EPI_BF16, dqkv, wqt, None)
+    dwq, dbq = _lin_grads(dqkv, ln)
+    dx, _, dnw, dnb = ops.layernorm_bwd(dln, x, n_w, mean, rstd, dres=g)
+    return dx, [dnw, dnb, dwq, dbq, dwp, dbp]
+
+
+class BlockFn(torch.autograd.Function):
+    """Pre-LN transformer block (multimae/multimae_utils.py:282-285 of the reference), x f32 [B,N,D]."""
+
+    @staticmethod
+    def forward(ctx, x, heads, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b):
+        B, N, D = x.shape
+        x2 = x.contiguous().reshape(B * N, D)
+        x1, s_att = _self_attn_fwd(x2, B, N, heads, n1w, n1b, qkvw, qkvb, pw, pb)
+        y, s_mlp = _mlp_fwd(x1, n2w, n2b, f1w, f1b, f2w, f2b)
+        ctx.saved = (s_att, s_mlp)
+        ctx.shape = (B, N, D)
+        return y.reshape(B, N, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, D = ctx.shape
+        s_att, s_mlp = ctx.saved
+        ctx.saved = None
+        g1, gm = _mlp_bwd(g.contiguous().reshape(B * N, D), s_mlp)
+        g0, ga = _self_attn_bwd(g1, s_att)
+        return (g0.reshape(B, N, D), None, *ga, *gm)
+
+
+# ---------------------------------------------------------------------------------------------
+# input side: masks, patch projection of the kept tokens, global tokens
+# ---------------------------------------------------------------------------------------------
+def round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+class EmbedFn(torch.autograd.Function):
+    """Kept-token patch embedding: Conv2d(k=s=P) + pos-emb + gather(ids_keep) + global tokens
+    (multimae/input_adapters.py:126-135, multimae/multimae.py:393-406 of the reference) -> x f32 [B, k+G, D].
+    Only the kept tokens are projected (the reference projects all of them and drops the rest)."""
+
+    @staticmethod
+    def forward(ctx, keep32, patch, pos_tables, global_tokens, n_img, *tensors):
+        images = tensors[:n_img]
+        weights = tensors[n_img:2 * n_img]
+        biases = tensors[2 * n_img:3 * n_img]
+        B = images[0].shape[0]
+        D = weights[0].shape[0]
+        k = keep32.shape[1]
+        G = global_tokens.shape[1]
+        ntok = pos_tables[0].shape[-1] * pos_tables[0].shape[-2]
+        widths = [w[0].numel() for w in weights]
+        kpatch = sum(widths)
+        ktot = round_up(kpatch + 8, 64)
+        a = ops.pack_patches([im.contiguous() for im in images], patch, keep32, ktot)
+        wcat = torch.zeros((D, ktot), dtype=torch.bfloat16, device=a.device)
+        off = 0
+        for w, n in zip(weights, widths):
+            wcat[:, off:off + n] = w.detach().reshape(D, n)
+            off += n
+        tab = ops.build_token_table([p.contiguous() for p in pos_tables], [b_.detach() for b_ in biases], ntok, D)
+        x = torch.empty((B, k + G, D), dtype=torch.float32, device=a.device)
+        if k > 0:
+            ops.patch_embed_gemm(a, wcat, keep32, tab, k, k + G, x)
+        ops.append_global(global_tokens.detach().contiguous(), x, k)
+        ctx.saved = (a, widths, [w.shape for w in weights], k, n_img)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        a, widths, wshapes, k, n_img = ctx.saved
+        ctx.saved = None
+        d_global, rows = ops.embed_bwd_reduce(dx.contiguous(), k)
+        dwcat = ops.gemm_tn(rows, a)  # [D, ktot]: patch columns, then the one-hot(domain) columns = bias grads
+        kpatch = sum(widths)
+        dws, dbs, off = [], [], 0
+        for t, (n, shp) in enumerate(zip(widths, wshapes)):
+            dws.append(dwcat[:, off:off + n].reshape(shp))
+            dbs.append(dwcat[:, kpatch + t].contiguous())
+            off += n
+        return (None, None, None, d_global, None, *([None] * n_img), *dws, *dbs)
+
+
+# ---------------------------------------------------------------------------------------------
+# decoder head: proj_context + query/context assembly + cross-attention + MLP
+# ---------------------------------------------------------------------------------------------
+class DecoderHeadFn(torch.autograd.Function):
+    """multimae/output_adapters.py:341-353 of the reference: enc f32 [B,k+G,D] -> x f32 [B,ntok,Dd]."""
+
+    @staticmethod
+    def forward(ctx, enc, keep32, restore32, meta, pos_table, mask_token, pc_w, pc_b, qn_w, qn_b, cn_w, cn_b, q_w, q_b,
+                kv_w, kv_b, pr_w, pr_b, on_w, on_b, f1w, f1b, f2w, f2b, *task_embs):
+        heads, k, G, T, ntok, q_start = meta
+        B, seq, D = enc.shape
+        Dd = pc_w.shape[0]
+        d = Dd // heads
+        enc_b = ops.cast_bf16(enc.contiguous().reshape(B * seq, D))
+        wpc, wpct = bf16_weights(pc_w)
+        ctxt = ops.gemm_nt(ops.EPI_BF16, enc_b, wpc, pc_b).reshape(B, seq, Dd)
+        emb = ops.build_decoder_emb([None if e is None else e.detach().contiguous() for e in task_embs], pos_table.contiguous(), ntok, Dd)
+        queries, context = ops.decoder_assemble_fwd(ctxt, mask_token.detach().contiguous(), emb, keep32, restore32, k, G, q_start, ntok)
+        qn, qmean, qrstd = ops.layernorm_fwd(queries.reshape(B * ntok, Dd), qn_w, qn_b)
+        cn, cmean, crstd = ops.layernorm_fwd(context.reshape(B * seq, Dd), cn_w, cn_b)
+        wq, wqt = bf16_weights(q_w)
+        wkv, wkvt = bf16_weights(kv_w)
+        wpr, wprt = bf16_weights(pr_w)
+        q = ops.gemm_nt(ops.EPI_BF16, qn, wq, q_b)
+        kv = ops.gemm_nt(ops.EPI_BF16, cn, wkv, kv_b)
+        o, lse = ops.attn_fwd(q, kv[:, :Dd], kv[:, Dd:], B, heads, ntok, seq, d, d ** -0.5)
+        x = ops.gemm_nt(ops.EPI_F32, o, wpr, pr_b)  # the cross-attention output replaces the queries (no residual)
+        y, s_mlp = _mlp_fwd(x, on_w, on_b, f1w, f1b, f2w, f2b)
+        ctx.saved = (s_mlp, o, lse, q, kv, qn, cn, queries, context, qmean, qrstd, cmean, crstd, qn_w, cn_w, enc_b,
+                     wqt, wkvt, wprt, wpct, keep32, restore32, meta, (B, seq, D, Dd), len(task_embs))
+        return y.reshape(B, ntok, Dd)
+
+    @staticmethod
+    def backward(ctx, g):
+        (s_mlp, o, lse, q, kv, qn, cn, queries, context, qmean, qrstd, cmean, crstd, qn_w, cn_w, enc_b,
+         wqt, wkvt, wprt, wpct, keep32, restore32, meta, dims, n_task) = ctx.saved
+        ctx.saved = None
+        heads, k, G, T, ntok, q_start = meta
+        B, seq, D, Dd = dims
+        d = Dd // heads
+        dx, g_mlp = _mlp_bwd(g.contiguous().reshape(B * ntok, Dd), s_mlp)
+        dxb = _bf16(dx)
+        d_o = ops.gemm_nt(ops.EPI_BF16, dxb, wprt, None)
+        dwpr, dbpr = _lin_grads(dxb, o)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        ops.attn_bwd(q, kv[:, :Dd], kv[:, Dd:], o, d_o, lse, dq, dkv[:, :Dd], dkv[:, Dd:], B, heads, ntok, seq, d, d ** -0.5)
+        dqn = ops.gemm_nt(ops.EPI_BF16, dq, wqt, None)
+        dwq, dbq = _lin_grads(dq, qn)
+        dcn = ops.gemm_nt(ops.EPI_BF16, dkv, wkvt, None)
+        dwkv, dbkv = _lin_grads(dkv, cn)
+        d_queries, _, dqnw, dqnb = ops.layernorm_bwd(dqn, queries.reshape(B * ntok, Dd), qn_w, qmean, qrstd)
+        d_context, _, dcnw, dcnb = ops.layernorm_bwd(dcn, context.reshape(B * seq, Dd), cn_w, cmean, crstd)
+        d_ctx, d_mask, d_task = ops.decoder_assemble_bwd(d_queries.reshape(B, ntok, Dd), d_context.reshape(B, seq, Dd), keep32,
+                                                         restore32, k, G, T, ntok, q_start, ntok)
+        d_ctx2 = d_ctx.reshape(B * seq, Dd)
+        d_enc = ops.gemm_nt(ops.EPI_F32, d_ctx2, wpct, None).reshape(B, seq, D)
+        dwpc, dbpc = _lin_grads(d_ctx2, enc_b)
+        dnw, dnb, df1w, df1b, df2w, df2b = g_mlp
+        return (d_enc, None, None, None, None, d_mask, dwpc, dbpc, dqnw, dqnb, dcnw, dcnb, dwq, dbq, dwkv, dbkv, dwpr, dbpr,
+                dnw, dnb, df1w, df1b, df2w, df2b, *d_task[:n_task])
+
+
+class OutProjFn(torch.autograd.Function):
+    """out_proj + un-patchify (multimae/output_adapters.py:361-372 of the reference): x f32 [B,ntok,Dd] -> bf16 [B,C,H,W]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, C_, P, NH, NW):
+        B, ntok, Dd = x.shape
+        xb = ops.cast_bf16(x.contiguous().reshape(B * ntok, Dd))
+        wb, wt = bf16_weights(w)
+        img = ops.unpatchify_gemm(xb, wb, b, B, C_, P, NH, NW)
+        ctx.saved = (xb, wt, (B, ntok, Dd, P))
+        return img
+
+    @staticmethod
+    def backward(ctx, dimg):
+        xb, wt, (B, ntok, Dd, P) = ctx.saved
+        ctx.saved = None
+        rows = ops.patchify_bf16(_bf16(dimg.contiguous()), P)
+        dx = ops.gemm_nt(ops.EPI_F32, rows, wt, None).reshape(B, ntok, Dd)
+        dw, db = _lin_grads(rows, xb)
+        return dx, dw, db, None, None, None, None
+
+
+class MaskedLossFn(torch.autograd.Function):
+    """Masked MSE / L1 (multimae/criterion.py:96-130, :161-195 of the reference); value and gradient from one kernel pass."""
+
+    @staticmethod
+    def forward(ctx, pred, target, mask, kind, norm_pix, patch):
+        loss, d_pred = ops.masked_loss(kind, norm_pix, pred.contiguous(), target.contiguous(), mask, patch, want_grad=True)
+        ctx.save_for_backward(d_pred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_pred,) = ctx.saved_tensors
+        return d_pred * g.to(d_pred.dtype), None, None, None, None, None

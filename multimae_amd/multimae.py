@@ -1,0 +1,228 @@
+"""MultiMAE with the reference's module API (multimae/multimae.py), evaluated by the HIP kernels.
+
+Order of work in forward differs from the reference where it saves work without changing results: the masks
+depend only on shapes and noise, so they are drawn first and the patch projection is evaluated for the kept
+tokens only."""
+import itertools
+import math
+from collections import OrderedDict
+from functools import partial
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+from torch import Tensor, nn
+from torch.distributions.dirichlet import Dirichlet
+
+from . import functional as Fn
+from . import ops
+from .input_adapters import PatchedInputAdapter
+from .multimae_utils import Block, trunc_normal_
+from .output_adapters import SpatialOutputAdapter
+
+__all__ = ["MultiMAE", "pretrain_multimae_base", "pretrain_multimae_large", "create_model"]
+
+
+class MultiMAE(nn.Module):
+    """Multi-modal masked autoencoder: per-domain patch adapters, Dirichlet-budgeted random masking, a ViT encoder
+    over the kept tokens plus global tokens, and one cross-attention decoder per output domain."""
+
+    def __init__(self, input_adapters: Dict[str, nn.Module], output_adapters: Optional[Dict[str, nn.Module]],
+                 num_global_tokens: int = 1, dim_tokens: int = 768, depth: int = 12, num_heads: int = 12,
+                 mlp_ratio: float = 4.0, qkv_bias: bool = True, drop_rate: float = 0.0, attn_drop_rate: float = 0.0,
+                 drop_path_rate: float = 0.0, norm_layer: nn.Module = partial(nn.LayerNorm, eps=1e-6)):
+        super().__init__()
+        for adapter in input_adapters.values():
+            adapter.init(dim_tokens=dim_tokens)
+        self.input_adapters = nn.ModuleDict(input_adapters)
+        if output_adapters is not None:
+            for adapter in output_adapters.values():
+                adapter.init(dim_tokens_enc=dim_tokens)
+            self.output_adapters = nn.ModuleDict(output_adapters)
+        else:
+            self.output_adapters = None
+
+        self.num_global_tokens = num_global_tokens
+        self.global_tokens = nn.Parameter(torch.zeros(1, num_global_tokens, dim_tokens))
+        trunc_normal_(self.global_tokens, std=0.02)
+
+        if drop_path_rate:
+            raise NotImplementedError("drop_path_rate > 0 is not implemented in the fused blocks")
+        self.encoder = nn.Sequential(*[
+            Block(dim=dim_tokens, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop=drop_rate,
+                  attn_drop=attn_drop_rate, drop_path=0.0, norm_layer=norm_layer) for _ in range(depth)])
+        self._reset_parameters()
+        self._last_ids_i32 = None
+
+    # -- initialisation (reference: multimae/multimae.py:117-146) ------------------------------------
+    def _reset_parameters(self):
+        def base(m):
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+        self.apply(base)
+        for name, m in self.named_modules():
+            if isinstance(m, nn.Linear):
+                # packed projections: each of the 3 (qkv) / 2 (kv) blocks gets its own xavier bound
+                parts = 3 if "qkv" in name else (2 if "kv" in name else 0)
+                if parts:
+                    bound = math.sqrt(6.0 / float(m.weight.shape[0] // parts + m.weight.shape[1]))
+                    nn.init.uniform_(m.weight, -bound, bound)
+            if isinstance(m, nn.Conv2d) and ".proj" in name:
+                nn.init.xavier_uniform_(m.weight.data.view(m.weight.shape[0], -1))
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        skip = {"global_tokens"}
+        for group, adapters in (("input_adapters", self.input_adapters), ("output_adapters", self.output_adapters or {})):
+            for task, adapter in adapters.items():
+                if hasattr(adapter, "no_weight_decay"):
+                    skip |= {f"{group}.{task}.{n}" for n in adapter.no_weight_decay()}
+        return skip
+
+    # -- masking (reference: multimae/multimae.py:169-253) ---------------------------------------------
+    def sample_alphas(self, B: int, n_tasks: int, alphas: float = 1.0, eps: float = 1e-5):
+        """Per sample, pick a non-empty subset of tasks uniformly; Dirichlet concentration = alphas on the subset, eps elsewhere."""
+        choices = torch.Tensor([list(c) for c in itertools.product([0, 1], repeat=n_tasks)][1:])
+        pick = torch.randint(0, len(choices), (B,))
+        return torch.index_select(choices, 0, pick) * torch.tensor(alphas) + eps
+
+    def generate_random_masks(self, input_tokens: Dict[str, torch.Tensor], num_encoded_tokens: int,
+                              alphas: Union[float, List[float]] = 1.0, sample_tasks_uniformly: bool = False,
+                              mask_randomness=None):
+        """Returns (task_masks {domain: [B,N_d] int64, 0 keep / 1 masked}, ids_keep [B,k] int64, ids_restore [B,sum N] int64).
+
+        Only shapes and device of `input_tokens` are used.  `mask_randomness` = (task_sampling_dist [B,T],
+        [noise_d [B,N_d]], noise_all [B,sum N]) replaces the draws (tests replay the reference's samples)."""
+        first = next(iter(input_tokens.values()))
+        B, device = first.shape[0], first.device
+        sizes = [t.shape[1] for t in input_tokens.values()]
+        if mask_randomness is not None:
+            p, noises, noise_all = mask_randomness
+            p, noise_all = p.to(device, torch.float32), noise_all.to(device, torch.float32)
+            noise = torch.cat([n.to(device, torch.float32) for n in noises], dim=1)
+        else:
+            al = [alphas] * len(sizes) if isinstance(alphas, float) else alphas
+            if sample_tasks_uniformly:
+                p = Dirichlet(self.sample_alphas(B, len(sizes), alphas=al)).sample().to(device)
+            else:
+                p = Dirichlet(torch.tensor(al, dtype=torch.float32, device=device)).sample((B,))
+            noise = torch.cat([torch.rand(B, n, device=device) for n in sizes], dim=1)
+            noise_all = torch.rand(B, sum(sizes), device=device)
+        mask, ids_keep, ids_restore, keep32, restore32 = ops.mask_generate(
+            p.contiguous(), noise.contiguous(), noise_all.contiguous(), sizes, int(num_encoded_tokens))
+        self._last_ids_i32 = (keep32, restore32)
+        task_masks = {d: m for d, m in zip(input_tokens.keys(), torch.split(mask, sizes, dim=1))}
+        return task_masks, ids_keep, ids_restore
+
+    @staticmethod
+    def make_mask(N_H, N_W, xy_idxs, full_tasks=[], indicate_visible=True, flatten=True, device="cuda"):
+        """Masks from lists of visible (x, y) token coordinates per task (reference: multimae/multimae.py:255-285)."""
+        masks = {}
+        for k, v in xy_idxs.items():
+            m = torch.ones(N_H, N_W, device=device)
+            idx = torch.LongTensor(v)
+            if len(idx) > 0:
+                m[idx[:, 1], idx[:, 0]] = 0
+            if k in full_tasks:
+                m[:] = 0
+            if not indicate_visible:
+                m = 1 - m
+            masks[k] = m.flatten().unsqueeze(0) if flatten else m
+        return masks
+
+    def generate_input_info(self, input_task_tokens: Dict[str, Tensor], image_size: Tuple[int, int]) -> Dict:
+        """start/end index of every domain in the concatenated token sequence (reference: multimae/multimae.py:287-312)."""
+        info = OrderedDict()
+        info["tasks"] = {}
+        start = 0
+        for domain, tensor in input_task_tokens.items():
+            n = int(tensor.shape[1])
+            info["tasks"][domain] = {"num_tokens": n, "has_2d_posemb": True, "start_idx": start, "end_idx": start + n}
+            start += n
+        info["image_size"] = image_size
+        info["num_task_tokens"] = start
+        info["num_global_tokens"] = self.num_global_tokens
+        return info
+
+    # -- forward (reference: multimae/multimae.py:314-438) ---------------------------------------------
+    def forward(self, x: Union[Dict[str, torch.Tensor], torch.Tensor], mask_inputs: bool = True,
+                task_masks: Dict[str, torch.Tensor] = None, num_encoded_tokens: int = 128,
+                alphas: Union[float, List[float]] = 1.0, sample_tasks_uniformly: bool = False,
+                fp32_output_adapters: List[str] = [], mask_randomness=None):
+        x = {"rgb": x} if isinstance(x, torch.Tensor) else x
+        B, _, H, W = (x["rgb"] if "rgb" in x else next(iter(x.values()))).shape
+        domains = [d for d in x if d in self.input_adapters]
+        adapters = [self.input_adapters[d] for d in domains]
+        for d, ad in zip(domains, adapters):
+            if not isinstance(ad, PatchedInputAdapter):
+                raise NotImplementedError(f"input adapter of '{d}': only PatchedInputAdapter feeds the fused patch-embed kernel")
+            if tuple(x[d].shape[-2:]) != (H, W) or ad.P_H != adapters[0].P_H:
+                raise NotImplementedError("all input domains must share the image size and the patch size")
+        nh, nw = adapters[0].grid(H, W)
+        device = x[domains[0]].device
+        specs = OrderedDict((d, torch.empty((B, nh * nw, 0), device=device)) for d in domains)
+        input_info = self.generate_input_info(specs, image_size=(H, W))
+
+        if not mask_inputs:
+            num_encoded_tokens = nh * nw * len(domains)
+        elif num_encoded_tokens is None:
+            num_encoded_tokens = self.num_encoded_tokens
+
+        if task_masks is None:
+            task_masks, ids_keep, ids_restore = self.generate_random_masks(
+                specs, num_encoded_tokens, alphas=alphas, sample_tasks_uniformly=sample_tasks_uniformly,
+                mask_randomness=mask_randomness)
+            keep32, restore32 = self._last_ids_i32
+        else:
+            mask_all = torch.cat([task_masks[d] for d in domains], dim=1)
+            ids_shuffle = torch.argsort(mask_all, dim=1, stable=True)
+            ids_restore = torch.argsort(ids_shuffle, dim=1, stable=True)
+            kept = (mask_all == 0).sum(dim=1)
+            if not bool((kept == kept[0]).all()):
+                raise ValueError("given task_masks must keep the same number of tokens in every sample")
+            ids_keep = ids_shuffle[:, : int(kept[0])]
+            keep32, restore32 = ids_keep.to(torch.int32).contiguous(), ids_restore.to(torch.int32).contiguous()
+        input_info["_ids_keep_i32"], input_info["_ids_restore_i32"] = keep32, restore32
+
+        tokens = Fn.EmbedFn.apply(keep32, adapters[0].P_H, [ad.pos_table(nh, nw) for ad in adapters], self.global_tokens,
+                                  len(domains), *[x[d] for d in domains], *[ad.proj.weight for ad in adapters],
+                                  *[ad.proj.bias for ad in adapters])
+        encoder_tokens = self.encoder(tokens)
+        if self.output_adapters is None:
+            return encoder_tokens, task_masks
+        if any(d in self.output_adapters for d in fp32_output_adapters):
+            raise NotImplementedError("fp32_output_adapters: the decoders have a single (bf16-operand) kernel path")
+        preds = {d: self.output_adapters[d](encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep,
+                                            ids_restore=ids_restore) for d in self.output_adapters}
+        return preds, task_masks
+
+
+_MODEL_REGISTRY = {}
+
+
+def register_model(fn):
+    _MODEL_REGISTRY[fn.__name__] = fn
+    return fn
+
+
+def create_model(model_name: str, **kwargs):
+    """Name -> factory lookup used by the reference's training scripts (utils/model_builder.py:29-79 there)."""
+    if model_name not in _MODEL_REGISTRY:
+        raise RuntimeError(f"Unknown model ({model_name})")
+    return _MODEL_REGISTRY[model_name](**kwargs)
+
+
+@register_model
+def pretrain_multimae_base(input_adapters: Dict[str, nn.Module], output_adapters: Optional[Dict[str, nn.Module]], **kwargs):
+    return MultiMAE(input_adapters=input_adapters, output_adapters=output_adapters, dim_tokens=768, depth=12, num_heads=12,
+                    mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+@register_model
+def pretrain_multimae_large(input_adapters: Dict[str, nn.Module], output_adapters: Optional[Dict[str, nn.Module]], **kwargs):
+    return MultiMAE(input_adapters=input_adapters, output_adapters=output_adapters, dim_tokens=1024, depth=24, num_heads=16,
+                    mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)

@@ -1,0 +1,126 @@
+"""Building blocks with the reference's class names and parameter layout (multimae/multimae_utils.py of the
+reference); the arithmetic runs in the HIP kernels through multimae_amd.functional."""
+import math
+
+import torch
+from torch import nn
+
+from . import functional as Fn
+
+
+def pair(t):
+    return t if isinstance(t, tuple) else (t, t)
+
+
+def build_2d_sincos_posemb(h, w, embed_dim=1024, temperature=10000.0):
+    """Fixed 2-D sin-cos table [1, embed_dim, h, w] (reference: multimae/multimae_utils.py:29-49).
+
+    Channel quarters are sin(a*w_j), cos(a*w_j), sin(b*w_j), cos(b*w_j) with w_j = temperature^(-j/(D/4)).
+    The reference flattens a (w, h) grid and re-reads it as (h, w), so for the flat position m = row*w + col
+    the coordinates are a = m // h and b = m % h; with h == w that makes `a` the image row."""
+    if embed_dim % 4:
+        raise ValueError("embed_dim must be divisible by 4 for the 2-D sin-cos embedding")
+    quarter = embed_dim // 4
+    freq = 1.0 / (temperature ** (torch.arange(quarter, dtype=torch.float32) / quarter))
+    m = torch.arange(h * w)
+    a = torch.div(m, h, rounding_mode="floor").float()[:, None] * freq[None, :]
+    b = (m % h).float()[:, None] * freq[None, :]
+    table = torch.cat([a.sin(), a.cos(), b.sin(), b.cos()], dim=1)
+    return table.reshape(h, w, embed_dim).permute(2, 0, 1).unsqueeze(0).contiguous()
+
+
+def trunc_normal_(tensor, mean=0.0, std=1.0, a=-2.0, b=2.0):
+    """In-place truncated normal through the inverse CDF (reference: multimae/multimae_utils.py:52-108)."""
+    def cdf(v):
+        return 0.5 * (1.0 + math.erf(v / math.sqrt(2.0)))
+    with torch.no_grad():
+        lo, hi = cdf((a - mean) / std), cdf((b - mean) / std)
+        tensor.uniform_(2 * lo - 1, 2 * hi - 1).erfinv_().mul_(std * math.sqrt(2.0)).add_(mean).clamp_(min=a, max=b)
+    return tensor
+
+
+def _no_dropout(**rates):
+    for name, r in rates.items():
+        if r:
+            raise NotImplementedError(f"{name}={r}: the HIP path implements the pretraining configuration (all drop rates 0)")
+
+
+class DropPath(nn.Module):
+    """Kept for API parity; only drop_prob == 0 (identity) is implemented."""
+
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        _no_dropout(drop_path=drop_prob)
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        return x
+
+
+class Mlp(nn.Module):
+    """fc1 -> exact GELU -> fc2 (reference: multimae/multimae_utils.py:145-169). Parameter container; the enclosing
+    Block / SpatialOutputAdapter runs it fused with its LayerNorm and residual."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        _no_dropout(drop=drop)
+        if act_layer is not nn.GELU:
+            raise NotImplementedError("only nn.GELU (erf form) is fused into the GEMM epilogue")
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+
+class Attention(nn.Module):
+    """qkv / proj parameters of multi-head self-attention (reference: multimae/multimae_utils.py:172-207)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        _no_dropout(attn_drop=attn_drop, proj_drop=proj_drop)
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class CrossAttention(nn.Module):
+    """q / kv / proj parameters of multi-head cross-attention (reference: multimae/multimae_utils.py:210-247)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        _no_dropout(attn_drop=attn_drop, proj_drop=proj_drop)
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+def _bias_or_zeros(lin: nn.Linear):
+    if lin.bias is not None:
+        return lin.bias
+    if not hasattr(lin, "_mmae_zero_bias") or lin._mmae_zero_bias.device != lin.weight.device:
+        lin._mmae_zero_bias = torch.zeros(lin.out_features, device=lin.weight.device)
+    return lin._mmae_zero_bias
+
+
+class Block(nn.Module):
+    """x + attn(norm1(x)); x + mlp(norm2(x))  (reference: multimae/multimae_utils.py:250-285), one fused autograd node."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, drop=0.0, attn_drop=0.0, drop_path=0.0,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        _no_dropout(drop_path=drop_path)
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        for n in (self.norm1, self.norm2):
+            if not isinstance(n, nn.LayerNorm) or abs(n.eps - 1e-6) > 1e-12:
+                raise NotImplementedError("the fused block expects nn.LayerNorm(eps=1e-6)")
+
+    def forward(self, x):
+        a, m = self.attn, self.mlp
+        return Fn.BlockFn.apply(x, a.num_heads, self.norm1.weight, self.norm1.bias, a.qkv.weight, _bias_or_zeros(a.qkv),
+                                a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias,
+                                m.fc2.weight, m.fc2.bias)

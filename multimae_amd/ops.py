@@ -234,6 +234,8 @@ def patch_embed_gemm(a: torch.Tensor, wcat: torch.Tensor, add_idx: torch.Tensor,
 
 def append_global(global_tokens: torch.Tensor, x: torch.Tensor, k: int):
     B, seq, dim = x.shape
+    if seq == k or B == 0:
+        return
     _lib.check(_L().mmae_append_global(_ptr(global_tokens), _ptr(x), B, k, seq - k, dim, _stream()), "append_global")
 
 
@@ -242,11 +244,11 @@ def embed_bwd_reduce(dx: torch.Tensor, k: int):
     _req(dx, F32, "embed_bwd dx")
     B, seq, dim = dx.shape
     G = seq - k
-    d_global = torch.empty((1, G, dim), dtype=F32, device=dx.device)
+    d_global = torch.empty((1, max(G, 1), dim), dtype=F32, device=dx.device)
     rows = torch.empty((B * k, dim), dtype=BF16, device=dx.device)
     _lib.check(_L().mmae_embed_bwd_reduce(_ptr(dx), None, B, k, G, dim, 0, 0, _ptr(d_global), None, _ptr(rows), _stream()),
                "embed_bwd_reduce")
-    return d_global, rows
+    return d_global[:, :G], rows
 
 
 def build_decoder_emb(task_embs: Sequence[Optional[torch.Tensor]], pos_emb: torch.Tensor, ntok: int, dd: int):

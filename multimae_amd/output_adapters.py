@@ -1,0 +1,118 @@
+"""Output adapters with the reference's constructor / init / forward contract (multimae/output_adapters.py:43-374).
+Only the cross-attention pretraining decoder is on the hot path; the finetuning heads of the reference
+(linear / ConvNeXt / DPT) are out of scope here."""
+from functools import partial
+from typing import Dict, Optional, Tuple, Union
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from . import functional as Fn
+from .multimae_utils import Block, CrossAttention, Mlp, build_2d_sincos_posemb, pair, trunc_normal_
+
+
+class SpatialOutputAdapter(nn.Module):
+    """Cross-attention decoder for image-like outputs.
+
+    proj_context -> (mask-token fill, un-shuffle, + task / position embeddings) -> queries = this task's slice
+    -> cross-attention over the kept tokens (its output replaces the queries) -> MLP -> `depth` self-attention
+    blocks -> out_proj -> image.  Parameter names and shapes follow the reference so state_dicts interchange."""
+
+    def __init__(self, num_channels: int, stride_level: int, patch_size_full: Union[int, Tuple[int, int]],
+                 dim_tokens_enc: Optional[int] = None, dim_tokens: int = 256, depth: int = 0, learnable_pos_emb: int = False,
+                 image_size: Union[int, Tuple[int]] = 224, mlp_ratio: int = 4.0, num_heads: int = 8, qkv_bias: bool = True,
+                 drop_rate: float = 0.0, attn_drop_rate: float = 0.0, drop_path_rate: float = 0.0,
+                 norm_layer: nn.Module = partial(nn.LayerNorm, eps=1e-6), use_task_queries: bool = True,
+                 task: Optional[str] = None, context_tasks: Optional[list] = None, use_xattn: bool = True):
+        super().__init__()
+        self.num_channels = num_channels
+        self.stride_level = stride_level
+        self.patch_size_full = pair(patch_size_full)
+        self.dim_tokens_enc = dim_tokens_enc
+        self.dim_tokens = dim_tokens
+        self.learnable_pos_emb = learnable_pos_emb
+        self.image_size = pair(image_size)
+        self.use_task_queries = use_task_queries
+        self.task = task
+        self.use_xattn = use_xattn
+        self.num_heads = num_heads
+        self.P_H = max(1, self.patch_size_full[0] // stride_level)
+        self.P_W = max(1, self.patch_size_full[1] // stride_level)
+        if not use_xattn or learnable_pos_emb or drop_path_rate or self.P_H != self.P_W:
+            raise NotImplementedError("the HIP decoder implements use_xattn=True, fixed sin-cos pos_emb, drop_path 0, square patches")
+
+        self.task_embeddings = None
+        if context_tasks is not None:
+            self.task_embeddings = nn.ParameterDict({t: nn.Parameter(torch.zeros(1, 1, dim_tokens)) for t in context_tasks})
+            for emb in self.task_embeddings.values():
+                trunc_normal_(emb, std=0.02)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, dim_tokens))
+        h = self.image_size[0] // (stride_level * self.P_H)
+        w = self.image_size[1] // (stride_level * self.P_W)
+        self.pos_emb = nn.Parameter(build_2d_sincos_posemb(h, w, dim_tokens), requires_grad=False)
+
+        self.decoder = CrossAttention(dim=dim_tokens, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop_rate,
+                                      proj_drop=drop_rate)
+        self.context_norm = norm_layer(dim_tokens)
+        self.query_norm = norm_layer(dim_tokens)
+        self.out_norm = norm_layer(dim_tokens)
+        self.mlp = Mlp(in_features=dim_tokens, hidden_features=int(dim_tokens * mlp_ratio))
+        if depth > 0:
+            self.decoder_transformer = nn.Sequential(*[
+                Block(dim=dim_tokens, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop=drop_rate,
+                      attn_drop=attn_drop_rate, drop_path=0.0, norm_layer=norm_layer) for _ in range(depth)])
+        else:
+            self.decoder_transformer = nn.Identity()
+        self.dim_patch = num_channels * self.P_H * self.P_W
+        self.out_proj = nn.Linear(dim_tokens, self.dim_patch)
+        if dim_tokens_enc is not None:
+            self.init(dim_tokens_enc=dim_tokens_enc)
+
+    def init(self, dim_tokens_enc: int = 768):
+        self.dim_tokens_enc = dim_tokens_enc
+        self.proj_context = nn.Linear(dim_tokens_enc, self.dim_tokens)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {"pos_emb", "mask_token", "task_embeddings"}
+
+    def _pos_table(self, nh: int, nw: int) -> Tensor:
+        if tuple(self.pos_emb.shape[-2:]) == (nh, nw):
+            return self.pos_emb
+        return F.interpolate(self.pos_emb, size=(nh, nw), mode="bilinear", align_corners=False)
+
+    def forward(self, encoder_tokens: Tensor, input_info: Dict, ids_keep: Tensor, ids_restore: Tensor):
+        assert self.dim_tokens_enc is not None, "Need to call init(dim_tokens_enc) function first"
+        H, W = input_info["image_size"]
+        nh = H // (self.stride_level * self.P_H)
+        nw = W // (self.stride_level * self.P_W)
+        tasks = list(input_info["tasks"].keys())
+        G = input_info.get("num_global_tokens", 0)
+        k = encoder_tokens.shape[1] - G
+        ntok = nh * nw
+        if not self.use_task_queries or self.task not in input_info["tasks"]:
+            raise NotImplementedError("the HIP decoder implements the task-query path (task must be one of the input domains)")
+        for t in tasks:
+            if input_info["tasks"][t]["num_tokens"] != ntok:
+                raise NotImplementedError("all input domains must have the same token grid as this decoder")
+        q_start = input_info["tasks"][self.task]["start_idx"]
+        keep32 = input_info.get("_ids_keep_i32")
+        restore32 = input_info.get("_ids_restore_i32")
+        if keep32 is None or restore32 is None:
+            keep32, restore32 = ids_keep.to(torch.int32).contiguous(), ids_restore.to(torch.int32).contiguous()
+        embs = [self.task_embeddings[t] if (self.task_embeddings is not None and t in self.task_embeddings) else None for t in tasks]
+        d, m = self.decoder, self.mlp
+        meta = (self.num_heads, k, G, len(tasks), ntok, q_start)
+        x = Fn.DecoderHeadFn.apply(
+            encoder_tokens, keep32, restore32, meta, self._pos_table(nh, nw), self.mask_token,
+            self.proj_context.weight, self.proj_context.bias, self.query_norm.weight, self.query_norm.bias,
+            self.context_norm.weight, self.context_norm.bias, d.q.weight, _b(d.q), d.kv.weight, _b(d.kv), d.proj.weight, d.proj.bias,
+            self.out_norm.weight, self.out_norm.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, *embs)
+        x = self.decoder_transformer(x)
+        return Fn.OutProjFn.apply(x, self.out_proj.weight, self.out_proj.bias, self.num_channels, self.P_H, nh, nw)
+
+
+def _b(lin: nn.Linear):
+    from .multimae_utils import _bias_or_zeros
+    return _bias_or_zeros(lin)

@@ -73,6 +73,13 @@ def tiny_cfg() -> dict:
                     dec_depth=1, dec_heads=4, patch=16, image=64)
 
 
+def small_cfg() -> dict:
+    """Smallest configuration the HIP kernels accept (head_dim 32 in encoder and decoders)."""
+    out = {"rgb": (3, "rgb"), "depth": (1, "depth"), "norm_rgb": (3, "rgb")}
+    return make_cfg({"rgb": 3, "depth": 1}, out, dim=128, depth=2, heads=4, dec_dim=64,
+                    dec_depth=1, dec_heads=2, patch=16, image=64)
+
+
 # --------------------------------------------------------------------------
 # positional embedding (multimae/multimae_utils.py:29-49)
 # --------------------------------------------------------------------------

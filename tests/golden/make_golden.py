@@ -130,8 +130,8 @@ def gen_posemb():
     print("posemb ok")
 
 
-def gen_tiny_e2e():
-    cfg = O.tiny_cfg()
+def gen_tiny_e2e(cfg=None, fname="tiny_e2e.npz"):
+    cfg = cfg or O.tiny_cfg()
     sd = G.perturbed_state(cfg, seed=7)
     model = build_ref_model(cfg)
     missing = model.load_state_dict(sd, strict=True)
@@ -172,8 +172,8 @@ def gen_tiny_e2e():
     for t in preds_b:
         out[f"bf16_loss_{t}"] = losses_fn[t](preds_b[t].float(), x[tgt[t]], mask=masks_b[tgt[t]]).detach().numpy()
     out["bf16_pred_depth"] = preds_b["depth"].float().detach().numpy()
-    np.savez_compressed(os.path.join(HERE, "tiny_e2e.npz"), **out)
-    print("tiny e2e ok; losses", {t: float(v) for t, v in losses.items()})
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, "ok; losses", {t: float(v) for t, v in losses.items()})
 
 
 def gen_losses():
@@ -269,6 +269,7 @@ if __name__ == "__main__":
     gen_masks()
     gen_posemb()
     gen_tiny_e2e()
+    gen_tiny_e2e(O.small_cfg(), "small_e2e.npz")
     gen_losses()
     gen_blocks()
     gen_depth_std()
