@@ -1,0 +1,148 @@
+"""Benchmark of the MultiMAE ViT-B/16 RGB-D pretraining step (forward, three masked losses, backward with bucketed
+gradient all-reduce, AdamW) on synthetic 224^2 tensors resident in HBM.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `value` = global images / second (max step time over ranks).  `roofline` is for the GEMM
+kernel family that takes the most time in the step, measured with HIP events around each of its launches in extra,
+untimed steps.  `cpu_baseline` (N=1 only) times the CPU restatement of the same step (oracle/, fp32, batch 4)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+STEP_GFLOP_PER_IMG = 62.33      # ViT-B RGB-D 224^2, 98 visible tokens, 3 decoders: 3 x forward MACs x 2 (GEMM + attention core)
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline():
+    """The oracle's CPU step (fp32, batch 4 = the reference's CPU-runnable configuration) on this host's cores."""
+    import torch
+    from oracle import multimae_oracle as O
+    cfg = O.vit_b_rgbd_cfg()
+    trainer = O.CpuTrainer(cfg, seed=0)
+    g = torch.Generator().manual_seed(1234)
+    B = 4
+    x = {"rgb": torch.randn(B, 3, 224, 224, generator=g), "depth": torch.rand(B, 1, 224, 224, generator=g)}
+    for _ in range(2):
+        trainer.step(x, 98, g)
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        trainer.step(x, 98, g)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(B / med, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "ViT-B/16 RGB-D 224^2, 98 visible tokens, 3 decoders, fp32, batch 4: median of 5 steps "
+                      "(fwd + 3 losses + bwd + AdamW) after 2 warm-up, oracle/multimae_oracle.py CpuTrainer"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from multimae_amd import ops
+    from multimae_amd.builders import build_losses, build_multimae
+    from multimae_amd.train import PretrainStep, init_distributed_mode
+
+    rank, world, local = init_distributed_mode("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    torch.manual_seed(0)  # identical initial weights on every rank (stands for DDP's rank-0 broadcast)
+    model = build_multimae().to(dev)
+    step = PretrainStep(model, build_losses(), num_encoded_tokens=98, alphas=1.0, lr=1e-4, weight_decay=0.05)
+    torch.manual_seed(1234 + rank)  # per-rank data / mask randomness (seed + rank, as the reference)
+    B = args.batch
+    batch = {"rgb": torch.randn(B, 3, 224, 224, device=dev), "depth": torch.rand(B, 1, 224, 224, device=dev)}
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss, _, _ = step(batch)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, task_losses, gn2 = step(batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+    if not (final_loss == final_loss and abs(final_loss) != float("inf")):
+        raise SystemExit(f"non-finite loss {final_loss}")
+    ms = elapsed / args.steps * 1e3
+    ips = world * B * args.steps / elapsed
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        ops.PROFILE = []
+        for _ in range(2):
+            step(batch)
+        torch.cuda.synchronize()
+        fam = {}
+        for name, flops, e0, e1 in ops.PROFILE:
+            d = fam.setdefault(name, [0.0, 0.0, 0])
+            d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
+        ops.PROFILE = None
+        name, (fl, sec, n) = max(fam.items(), key=lambda kv: kv[1][1])
+        ach = fl / sec / 1e12
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": n // 2,
+                "avg_launch_us": round(sec / n * 1e6, 1),
+                "families": {k_: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / 2 * 1e3, 3),
+                                  "launches_per_step": v[2] // 2} for k_, v in fam.items()}}
+    elif world > 1:
+        pass
+
+    if rank == 0:
+        out = {
+            "metric": "pretrain images/sec (node), MultiMAE ViT-B/16 RGB-D 224^2",
+            "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": "MultiMAE ViT-B/16 RGB+depth 224^2, 98 visible tokens, 3 decoders (rgb, depth, norm_rgb), "
+                                   "bf16 operands / fp32 accumulate, fwd + losses + bwd + grad all-reduce + AdamW",
+                       "per_gpu_batch": B, "global_batch": world * B, "num_encoded_tokens": 98, "parallelism": f"dp{world}"},
+            "step_gflop_per_image": STEP_GFLOP_PER_IMG,
+            "step_mfma_roofline_frac": round(ips * STEP_GFLOP_PER_IMG * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+            "final_loss": round(final_loss, 5),
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

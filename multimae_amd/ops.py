@@ -42,6 +42,29 @@ def _rows2d(t: torch.Tensor, name: str):
     return t.shape[0], t.shape[1], t.stride(0)
 
 
+# When set to a list, every GEMM / attention launch appends (kernel family, algorithmic FLOPs, start event, end event);
+# bench.py uses it to time the kernels with HIP events on the stream they run on.
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, name, flops):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append((self.name, self.flops, self.e0, self.e1))
+        return False
+
+
 _WS = {}
 
 
@@ -78,8 +101,9 @@ def gemm_nt(epi: int, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Ten
         _, _, ldaux = _rows2d(aux, "gemm_nt aux")
     if bias is not None:
         _req(bias, F32, "gemm_nt bias")
-    _lib.check(_L().mmae_gemm_nt(epi, _ptr(a), lda, _ptr(w), ldw, M, N, K, _ptr(bias), _ptr(out), ldo, _ptr(out2),
-                                 _ptr(aux), ldaux, _stream()), "gemm_nt")
+    with _Timed("gemm_nt", 2.0 * M * N * K):
+        _lib.check(_L().mmae_gemm_nt(epi, _ptr(a), lda, _ptr(w), ldw, M, N, K, _ptr(bias), _ptr(out), ldo, _ptr(out2),
+                                     _ptr(aux), ldaux, _stream()), "gemm_nt")
     return (out, out2) if epi == EPI_GELU else out
 
 
@@ -98,8 +122,9 @@ def gemm_tn(x: torch.Tensor, y: torch.Tensor, out: Optional[torch.Tensor] = None
         _req(out, F32, "gemm_tn out")
     nbytes = _L().mmae_gemm_tn_workspace_bytes(M, N, K)
     ws = workspace(nbytes, x.device)
-    _lib.check(_L().mmae_gemm_tn(_ptr(x), ldx, _ptr(y), ldy, M, N, K, _ptr(out), int(accumulate), _ptr(ws), ws.numel(),
-                                 _stream()), "gemm_tn")
+    with _Timed("gemm_tn", 2.0 * M * N * K):
+        _lib.check(_L().mmae_gemm_tn(_ptr(x), ldx, _ptr(y), ldy, M, N, K, _ptr(out), int(accumulate), _ptr(ws), ws.numel(),
+                                     _stream()), "gemm_tn")
     return out
 
 
@@ -160,9 +185,10 @@ def attn_fwd(q, k, v, B, H, q_len, kv_len, head_dim, scale):
         _req(t, BF16, f"attn_fwd {n}", contiguous=False)
     o = torch.empty((B * q_len, H * head_dim), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, q_len), dtype=F32, device=q.device)
-    _lib.check(_L().mmae_attn_fwd(_ptr(q), _head_view(q, "q"), _ptr(k), _head_view(k, "k"), _ptr(v), _head_view(v, "v"),
-                                  _ptr(o), o.stride(0), _ptr(lse), B, H, q_len, kv_len, head_dim, float(scale), _stream()),
-               "attn_fwd")
+    with _Timed("attn_fwd", 4.0 * B * H * q_len * kv_len * head_dim):
+        _lib.check(_L().mmae_attn_fwd(_ptr(q), _head_view(q, "q"), _ptr(k), _head_view(k, "k"), _ptr(v), _head_view(v, "v"),
+                                      _ptr(o), o.stride(0), _ptr(lse), B, H, q_len, kv_len, head_dim, float(scale), _stream()),
+                   "attn_fwd")
     return o, lse
 
 
@@ -171,10 +197,11 @@ def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, q_len, kv_len, head_dim, sc
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (d_o, "dO"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
         _req(t, BF16, f"attn_bwd {n}", contiguous=False)
     _req(lse, F32, "attn_bwd lse")
-    _lib.check(_L().mmae_attn_bwd(_ptr(q), _head_view(q, "q"), _ptr(k), _head_view(k, "k"), _ptr(v), _head_view(v, "v"),
-                                  _ptr(o), _head_view(o, "o"), _ptr(d_o), _head_view(d_o, "dO"), _ptr(lse),
-                                  _ptr(dq), _head_view(dq, "dq"), _ptr(dk), _head_view(dk, "dk"), _ptr(dv), _head_view(dv, "dv"),
-                                  B, H, q_len, kv_len, head_dim, float(scale), _stream()), "attn_bwd")
+    with _Timed("attn_bwd", 8.0 * B * H * q_len * kv_len * head_dim):
+        _lib.check(_L().mmae_attn_bwd(_ptr(q), _head_view(q, "q"), _ptr(k), _head_view(k, "k"), _ptr(v), _head_view(v, "v"),
+                                      _ptr(o), _head_view(o, "o"), _ptr(d_o), _head_view(d_o, "dO"), _ptr(lse),
+                                      _ptr(dq), _head_view(dq, "dq"), _ptr(dk), _head_view(dk, "dk"), _ptr(dv), _head_view(dv, "dv"),
+                                      B, H, q_len, kv_len, head_dim, float(scale), _stream()), "attn_bwd")
 
 
 # --------------------------------------------------------------------------------------------- masking
@@ -227,8 +254,9 @@ def patch_embed_gemm(a: torch.Tensor, wcat: torch.Tensor, add_idx: torch.Tensor,
                      seg_out: int, out: torch.Tensor):
     M, K = a.shape
     N = wcat.shape[0]
-    _lib.check(_L().mmae_patch_embed_gemm(_ptr(a), _ptr(wcat), M, N, K, _ptr(add_idx), _ptr(add_tab), seg_in, seg_out,
-                                          _ptr(out), out.shape[-1], _stream()), "patch_embed_gemm")
+    with _Timed("gemm_nt", 2.0 * M * N * K):
+        _lib.check(_L().mmae_patch_embed_gemm(_ptr(a), _ptr(wcat), M, N, K, _ptr(add_idx), _ptr(add_tab), seg_in, seg_out,
+                                              _ptr(out), out.shape[-1], _stream()), "patch_embed_gemm")
     return out
 
 
@@ -288,8 +316,9 @@ def unpatchify_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int
     M, K, lda = _rows2d(a, "unpatchify a")
     N = w.shape[0]
     img = torch.empty((B, C_, NH * P, NW * P), dtype=BF16, device=a.device)
-    _lib.check(_L().mmae_unpatchify_gemm(_ptr(a), lda, _ptr(w), M, N, K, _ptr(bias), _ptr(img), C_, P, NH, NW, _stream()),
-               "unpatchify_gemm")
+    with _Timed("gemm_nt", 2.0 * M * N * K):
+        _lib.check(_L().mmae_unpatchify_gemm(_ptr(a), lda, _ptr(w), M, N, K, _ptr(bias), _ptr(img), C_, P, NH, NW, _stream()),
+                   "unpatchify_gemm")
     return img
 
 

@@ -1,0 +1,192 @@
+"""Step-side runtime: flat parameter / gradient storage, fused AdamW, and data-parallel gradient exchange.
+
+Replaces, for the pretraining step, the reference's DistributedDataParallel wrap (run_pretraining_multimae.py:224-226),
+its NCCL bring-up (utils/dist.py:66-108) and the optimizer step inside NativeScalerWithGradNormCount
+(utils/native_scaler.py:23-51).  bf16 needs no loss scaling, so there is no GradScaler.
+
+Layout: every trainable parameter is a view into one fp32 buffer, ordered [decayed | not decayed], each region in
+reverse registration order (the order in which backward produces gradients), so that a bucket of the gradient
+buffer is complete as soon as backward has passed its last parameter.  Gradients are views into a second buffer of
+the same layout; buckets are all-reduced (SUM) over RCCL as they complete, overlapped with the rest of backward,
+and the 1/world factor is folded into the optimizer kernel."""
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import functional as Fn
+from . import ops
+
+
+def init_distributed_mode(backend: str = "nccl"):
+    """Environment-variable rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), one process per GPU.
+    Returns (rank, world_size, local_rank). Mirrors init_distributed_mode of the reference (utils/dist.py:66-108 there)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.barrier()
+    return rank, world, local
+
+
+def split_decay(model: torch.nn.Module):
+    """(decayed, not decayed) trainable parameters: no decay for 1-D tensors and the names in model.no_weight_decay()
+    (the usual rule of the reference family's optimizer factory, which is not part of the reference tree)."""
+    skip = set(model.no_weight_decay()) if hasattr(model, "no_weight_decay") else set()
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if p.ndim <= 1 or name.endswith(".bias") or any(name == s or name.startswith(s + ".") for s in skip):
+            no_decay.append((name, p))
+        else:
+            decay.append((name, p))
+    return decay, no_decay
+
+
+class FlatParams:
+    """Moves the trainable parameters of `model` into one flat fp32 buffer (and their .grad into another)."""
+
+    def __init__(self, model: torch.nn.Module):
+        decay, no_decay = split_decay(model)
+        decay, no_decay = decay[::-1], no_decay[::-1]
+        self.named = decay + no_decay
+        dev = self.named[0][1].device
+
+        def padded(n):  # keep every view 16-byte aligned
+            return (n + 3) // 4 * 4
+        self.offsets, off = [], 0
+        for _, p in decay:
+            self.offsets.append(off)
+            off += padded(p.numel())
+        self.n_decay = off
+        for _, p in no_decay:
+            self.offsets.append(off)
+            off += padded(p.numel())
+        self.numel = off
+        self.params = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for (name, p), o in zip(self.named, self.offsets):
+                view = self.params[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.grads[o:o + p.numel()].view(p.shape)
+        Fn.clear_weight_cache()
+
+    def zero_grad(self):
+        self.grads.zero_()
+        for (_, p), o in zip(self.named, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * o:
+                p.grad = self.grads[o:o + p.numel()].view(p.shape)  # re-attach after zero_grad(set_to_none=True)
+
+
+class GradBuckets:
+    """Bucketed SUM all-reduce of FlatParams.grads, launched from post-accumulate-grad hooks as buckets complete."""
+
+    def __init__(self, flat: FlatParams, bucket_mb: float = 64.0, group=None):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        cap = int(bucket_mb * (1 << 20) / 4)
+        self.buckets: List[List[int]] = []   # [start, end, n_params]
+        self.bucket_of = {}
+        cur = None
+        for i, ((_, p), o) in enumerate(zip(flat.named, flat.offsets)):
+            end = o + (p.numel() + 3) // 4 * 4
+            boundary = (o == flat.n_decay)  # never mix the two regions
+            if cur is None or boundary or end - cur[0] > cap:
+                cur = [o, end, 0]
+                self.buckets.append(cur)
+            cur[1] = end
+            cur[2] += 1
+            self.bucket_of[i] = len(self.buckets) - 1
+        self.pending = [b[2] for b in self.buckets]
+        self.works = []
+        self.enabled = self.world > 1
+        if self.enabled:
+            for i, (_, p) in enumerate(flat.named):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(_p):
+            b = self.bucket_of[i]
+            self.pending[b] -= 1
+            if self.pending[b] == 0:
+                s, e, _ = self.buckets[b]
+                self.works.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return hook
+
+    def finish(self):
+        """Call after backward: launches any bucket whose parameters received no gradient, waits for all."""
+        if not self.enabled:
+            return
+        for b, left in enumerate(self.pending):
+            if left > 0:
+                s, e, _ = self.buckets[b]
+                self.works.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in self.works:
+            w.wait()
+        self.works = []
+        self.pending = [b[2] for b in self.buckets]
+
+
+class FlatAdamW:
+    """AdamW over FlatParams in one kernel launch (PyTorch AdamW semantics; betas / weight decay as the reference's
+    pretraining defaults, pretrain_argparser.py:44-64 there)."""
+
+    def __init__(self, flat: FlatParams, lr=1e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05):
+        self.flat = flat
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(flat.params)
+        self.exp_avg_sq = torch.zeros_like(flat.params)
+        self.step_count = 0
+
+    def step(self, grad_scale: float = 1.0):
+        self.step_count += 1
+        ops.adamw_flat(self.flat.params, self.flat.grads, self.exp_avg, self.exp_avg_sq, self.flat.n_decay, self.lr,
+                       self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale)
+        Fn.bump_weight_epoch()
+
+    def grad_norm_sq(self):
+        return ops.sumsq(self.flat.grads)
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr,
+                "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+class PretrainStep:
+    """model + losses + flat AdamW + gradient buckets: one call = one optimisation step on a batch already on the device."""
+
+    def __init__(self, model, losses, num_encoded_tokens=98, alphas=1.0, lr=1e-4, weight_decay=0.05, betas=(0.9, 0.95),
+                 bucket_mb=64.0):
+        self.model, self.losses = model, losses
+        self.k, self.alphas = num_encoded_tokens, alphas
+        self.flat = FlatParams(model)
+        self.buckets = GradBuckets(self.flat, bucket_mb=bucket_mb)
+        self.opt = FlatAdamW(self.flat, lr=lr, betas=betas, weight_decay=weight_decay)
+        self.world = self.buckets.world
+
+    def __call__(self, batch, mask_randomness=None):
+        self.flat.zero_grad()
+        preds, masks = self.model(batch, num_encoded_tokens=self.k, alphas=self.alphas, mask_randomness=mask_randomness)
+        task_losses = {t: fn(preds[t], batch[tgt], mask=masks.get(tgt)) for t, (fn, tgt) in self.losses.items()}
+        loss = sum(task_losses.values())
+        loss.backward()
+        self.buckets.finish()
+        gn2 = self.opt.grad_norm_sq()
+        self.opt.step(grad_scale=1.0 / self.world)
+        return loss.detach(), task_losses, gn2
