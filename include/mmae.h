@@ -63,10 +63,11 @@ int mmae_unpatchify_gemm(const void* A, long lda, const void* W, int M, int N, i
 
 /* mmae_gemm_tn: out[N,K] (f32) (+)= X[M,N]^T x Y[M,K]: the weight-gradient half of nn.Linear backward
  * (dW = dC^T x A).  Split over M into fp32 slabs held in `workspace`, then reduced in a fixed order
- * (bitwise reproducible). */
+ * (bitwise reproducible).  If colsum_out != NULL it also receives (+)= the column sums of X (the bias
+ * gradient), computed by the same kernel. */
 size_t mmae_gemm_tn_workspace_bytes(int M, int N, int K);
 int mmae_gemm_tn(const void* X, long ldx, const void* Y, long ldy, int M, int N, int K, float* out, int accumulate,
-                 void* workspace, size_t workspace_bytes, mmae_stream_t stream);
+                 float* colsum_out, int colsum_accumulate, void* workspace, size_t workspace_bytes, mmae_stream_t stream);
 
 /* Column sums of a bf16 matrix: bias gradient of nn.Linear. */
 size_t mmae_colsum_workspace_bytes(int M, int N);

@@ -18,7 +18,7 @@ SIGNATURES = {
     "mmae_patch_embed_gemm": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _p, _l, _p]),
     "mmae_unpatchify_gemm": (_i, [_p, _l, _p, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p]),
     "mmae_gemm_tn_workspace_bytes": (_z, [_i, _i, _i]),
-    "mmae_gemm_tn": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _i, _p, _z, _p]),
+    "mmae_gemm_tn": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _i, _p, _i, _p, _z, _p]),
     "mmae_colsum_workspace_bytes": (_z, [_i, _i]),
     "mmae_colsum_bf16": (_i, [_p, _l, _i, _i, _p, _i, _p, _z, _p]),
     "mmae_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),

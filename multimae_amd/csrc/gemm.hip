@@ -11,6 +11,7 @@
 #define BN 128
 #define BKT 64            // k elements per stage
 #define TILE_BYTES 16384  // 128 rows x 64 bf16
+#define RASTER_M 8
 
 __device__ uint4 g_zero_page[4];  // 64 bytes of zeros: DMA source for out-of-range rows / k chunks
 
@@ -45,7 +46,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
     const int tiles_n = (p.N + BN - 1) / BN;
     const int nblk = gridDim.x;
     const int wg = xcd_remap(blockIdx.x, nblk);
-    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+    // walk the tiles in groups of RASTER_M row-tiles x all column-tiles, rows fastest: the workgroups in flight on one
+    // XCD then share a few A panels and a few W panels that fit its L2
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int per_group = RASTER_M * tiles_n;
+    const int grp = wg / per_group, within = wg - grp * per_group;
+    int gm_rows = tiles_m - grp * RASTER_M; gm_rows = gm_rows < RASTER_M ? gm_rows : RASTER_M;
+    const int m0 = (grp * RASTER_M + within % gm_rows) * BM, n0 = (within / gm_rows) * BN;
 
     // staging: wave-instruction j of this wave fills LDS rows (j*4+wave)*8 .. +7 (8 lanes per 128-B row)
     const bf16* a_src[4];
@@ -252,6 +259,7 @@ struct GemmTN {
     int rows_per_split;       // multiple of TN_ROWS
     float* out;               // [splits][N][K] slabs (or the final [N,K] when splits == 1)
     long slab;                // elements per slab
+    float* colsum;            // optional: [splits][N] column sums of X (bias gradient), same slab scheme
 };
 
 __device__ __forceinline__ int tn_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -301,6 +309,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // column sums of X ride along as one more MFMA per column fragment with an all-ones A operand
+    // (every row of that product is sum_m X[m][n]); only the wk == 0 waves of the k-tile-0 workgroups do it
+    const bool do_colsum = p.colsum != nullptr && k0 == 0 && wk == 0;
+    f32x4 csum[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) csum[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
     const int nsteps = (m_end - m_begin + TN_ROWS - 1) / TN_ROWS;
     if (nsteps > 0) {
@@ -336,6 +354,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
                     acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[ki], xf[ni], acc[ki][ni], 0, 0, 0);
+            if (do_colsum) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) csum[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[ni], csum[ni], 0, 0, 0);
+            }
         }
         __syncthreads();
         cur ^= 1;
@@ -352,16 +374,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
             if (k >= p.K) continue;
             *(f32x4*)(out + (long)n * p.K + k) = acc[ki][ni];
         }
+        if (do_colsum && g == 0) p.colsum[(long)split * p.N + n] = csum[ni][0];
     }
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i]
+// out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i]; the same for the column-sum slabs (scalar tail loop)
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab, int nsplit, float* __restrict__ out,
-                                   long n4, int accumulate) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+                                   long n4, int accumulate, const float* __restrict__ cslabs, int n_cols,
+                                   float* __restrict__ cout, int c_accumulate) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+    for (long i = tid; i < n4; i += nth) {
         f32x4 s = accumulate ? ((const f32x4*)out)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < nsplit; ++k) s += ((const f32x4*)(slabs + k * slab))[i];
         ((f32x4*)out)[i] = s;
+    }
+    if (cout) {
+        for (long i = tid; i < n_cols; i += nth) {
+            float s = c_accumulate ? cout[i] : 0.f;
+            for (int k = 0; k < nsplit; ++k) s += cslabs[(long)k * n_cols + i];
+            cout[i] = s;
+        }
     }
 }
 
@@ -375,11 +407,12 @@ static int tn_splits(int M, int N, int K) {
 }
 
 extern "C" size_t mmae_gemm_tn_workspace_bytes(int M, int N, int K) {
-    return (size_t)tn_splits(M, N, K) * (size_t)N * (size_t)K * sizeof(float);
+    return (size_t)tn_splits(M, N, K) * ((size_t)N * (size_t)K + (size_t)N) * sizeof(float);
 }
 
 extern "C" int mmae_gemm_tn(const void* X, long ldx, const void* Y, long ldy, int M, int N, int K, float* out,
-                            int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                            int accumulate, float* colsum_out, int colsum_accumulate, void* workspace,
+                            size_t workspace_bytes, hipStream_t stream) {
     MMAE_REQUIRE(X && Y && out, MMAE_EINVAL, "gemm_tn: null pointer");
     MMAE_REQUIRE(M > 0 && N >= 8 && K >= 8, MMAE_EINVAL, "gemm_tn: bad problem M=%d N=%d K=%d", M, N, K);
     MMAE_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= N && ldy >= K, MMAE_ESHAPE,
@@ -387,8 +420,8 @@ extern "C" int mmae_gemm_tn(const void* X, long ldx, const void* Y, long ldy, in
     MMAE_REQUIRE(((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0) && ((uintptr_t)out % 16 == 0), MMAE_EINVAL,
                  "gemm_tn: pointers must be 16-byte aligned");
     const int s = tn_splits(M, N, K);
-    const bool direct = (s == 1 && !accumulate);
-    const size_t need = direct ? 0 : (size_t)s * N * K * sizeof(float);
+    const bool direct = (s == 1 && !accumulate && !(colsum_out && colsum_accumulate));
+    const size_t need = direct ? 0 : mmae_gemm_tn_workspace_bytes(M, N, K);
     MMAE_REQUIRE(workspace_bytes >= need && (need == 0 || workspace), MMAE_EWORKSPACE,
                  "gemm_tn: workspace %zu bytes < required %zu", workspace_bytes, need);
     GemmTN p = {};
@@ -397,14 +430,17 @@ extern "C" int mmae_gemm_tn(const void* X, long ldx, const void* Y, long ldy, in
     p.rows_per_split = rps;
     p.slab = (long)N * K;
     float* tmp = direct ? out : (float*)workspace;
+    float* ctmp = colsum_out ? (direct ? colsum_out : (float*)workspace + (size_t)s * N * K) : nullptr;
     p.out = tmp;
+    p.colsum = ctmp;
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, s), dim3(256), 0, stream, p);
     MMAE_CHECK_LAUNCH("gemm_tn");
     if (!direct) {
         const long n4 = (long)N * K / 4;
         int blocks = (int)((n4 + 255) / 256); blocks = blocks > 2048 ? 2048 : blocks;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, tmp, p.slab, s, out, n4, accumulate);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, tmp, p.slab, s, out, n4, accumulate,
+                           ctmp, N, colsum_out, colsum_accumulate);
         MMAE_CHECK_LAUNCH("slab_reduce");
     }
     return MMAE_OK;

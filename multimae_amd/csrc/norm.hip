@@ -123,14 +123,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
     }
 }
 
-__global__ void ln_param_reduce_kernel(const float* __restrict__ part, int nblocks, int dim, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * dim) return;
+// column sums of the per-block partial rows: 64 columns x 4 row groups per block, fixed order
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, int nblocks, int dim,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              int accumulate) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float t = 0.f;
-    for (int b = 0; b < nblocks; ++b) t += part[(long)b * 2 * dim + c];
-    float* dst = c < dim ? dgamma + c : dbeta + (c - dim);
-    *dst = accumulate ? *dst + t : t;
+    if (c < 2 * dim)
+        for (int b = rg; b < nblocks; b += 4) t += part[(long)b * 2 * dim + c];
+    red[rg][cl] = t;
+    __syncthreads();
+    if (rg == 0 && c < 2 * dim) {
+        t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        float* dst = c < dim ? dgamma + c : dbeta + (c - dim);
+        *dst = accumulate ? *dst + t : t;
+    }
 }
 
 static int ln_bwd_blocks(int rows) {
@@ -164,7 +173,7 @@ extern "C" int mmae_layernorm_bwd(const void* dy, const float* x, const float* g
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const bf16*)dy, x, gamma, mean, rstd, dres, dx,
                        (bf16*)dx_bf16, (float*)workspace, rows, dim);
     MMAE_CHECK_LAUNCH("layernorm_bwd");
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * dim + 255) / 256), dim3(256), 0, stream, (const float*)workspace, nb, dim,
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * dim + 63) / 64), dim3(256), 0, stream, (const float*)workspace, nb, dim,
                        dgamma, dbeta, accumulate);
     MMAE_CHECK_LAUNCH("ln_param_reduce");
     return MMAE_OK;

@@ -42,9 +42,42 @@ def _bf16(g: torch.Tensor) -> torch.Tensor:
     return g if g.dtype == torch.bfloat16 else ops.cast_bf16(g.contiguous())
 
 
-def _lin_grads(dy_b: torch.Tensor, x_b: torch.Tensor):
-    """(dW [N,K] f32, db [N] f32) of y = x W^T + b from bf16 dy [M,N] and x [M,K]."""
-    return ops.gemm_tn(dy_b, x_b), ops.colsum(dy_b)
+def _direct(p) -> bool:
+    """True when the parameter's gradient lives in flat storage that the kernels may accumulate into directly
+    (set up by multimae_amd.train.FlatParams); autograd's own accumulation step is then skipped for it."""
+    return p is not None and getattr(p, "_mmae_direct", False) and p.grad is not None
+
+
+def _ready(p):
+    cb = getattr(p, "_mmae_ready", None) if p is not None else None
+    if cb is not None:
+        cb()
+
+
+def _lin_grads(dy_b: torch.Tensor, x_b: torch.Tensor, w=None, b=None):
+    """(dW [N,K] f32, db [N] f32) of y = x W^T + b from bf16 dy [M,N] and x [M,K]; (None, None) when they were
+    accumulated straight into w.grad / b.grad."""
+    want_b = b is not None and b.requires_grad
+    if _direct(w) and (not want_b or _direct(b)):
+        ops.gemm_tn(dy_b, x_b, out=w.grad, accumulate=True, colsum_out=b.grad if want_b else None, colsum_accumulate=True)
+        _ready(w)
+        if want_b:
+            _ready(b)
+        return None, None
+    if want_b:
+        return ops.gemm_tn(dy_b, x_b, colsum_out=True)
+    return ops.gemm_tn(dy_b, x_b), None
+
+
+def _ln_bwd(dy, x, n_w, n_b, mean, rstd, dres=None):
+    """LayerNorm backward; (dx, dgamma, dbeta) with the parameter gradients None when written in place."""
+    if _direct(n_w) and _direct(n_b):
+        dx = ops.layernorm_bwd(dy, x, n_w, mean, rstd, dres=dres, dgamma=n_w.grad, dbeta=n_b.grad)[0]
+        _ready(n_w)
+        _ready(n_b)
+        return dx, None, None
+    dx, _, dg, db = ops.layernorm_bwd(dy, x, n_w, mean, rstd, dres=dres)
+    return dx, dg, db
 
 
 # ---------------------------------------------------------------------------------------------
@@ -57,18 +90,18 @@ def _mlp_fwd(x, n_w, n_b, fc1_w, fc1_b, fc2_w, fc2_b):
     w2, w2t = bf16_weights(fc2_w)
     h, act = ops.gemm_nt(ops.EPI_GELU, ln, w1, fc1_b)
     y = ops.gemm_nt(ops.EPI_RESID, act, w2, fc2_b, aux=x)
-    return y, (x, ln, mean, rstd, h, act, w1t, w2t, n_w)
+    return y, (x, ln, mean, rstd, h, act, w1t, w2t, (n_w, n_b, fc1_w, fc1_b, fc2_w, fc2_b))
 
 
 def _mlp_bwd(g, saved):
     """g f32 [M,D] (gradient of the block output) -> (dx f32, [dn_w, dn_b, dfc1_w, dfc1_b, dfc2_w, dfc2_b])."""
-    x, ln, mean, rstd, h, act, w1t, w2t, n_w = saved
+    x, ln, mean, rstd, h, act, w1t, w2t, (n_w, n_b, fc1_w, fc1_b, fc2_w, fc2_b) = saved
     gb = _bf16(g)
     dh = ops.gemm_nt(ops.EPI_DGELU, gb, w2t, None, aux=h)
-    dw2, db2 = _lin_grads(gb, act)
+    dw2, db2 = _lin_grads(gb, act, fc2_w, fc2_b)
     dln = ops.gemm_nt(ops.EPI_BF16, dh, w1t, None)
-    dw1, db1 = _lin_grads(dh, ln)
-    dx, _, dnw, dnb = ops.layernorm_bwd(dln, x, n_w, mean, rstd, dres=g)
+    dw1, db1 = _lin_grads(dh, ln, fc1_w, fc1_b)
+    dx, dnw, dnb = _ln_bwd(dln, x, n_w, n_b, mean, rstd, dres=g)
     return dx, [dnw, dnb, dw1, db1, dw2, db2]
 
 
@@ -81,22 +114,22 @@ def _self_attn_fwd(x, B, N, heads, n_w, n_b, qkv_w, qkv_b, proj_w, proj_b):
     qkv = ops.gemm_nt(ops.EPI_BF16, ln, wq, qkv_b)
     o, lse = ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, heads, N, N, d, d ** -0.5)
     y = ops.gemm_nt(ops.EPI_RESID, o, wp, proj_b, aux=x)
-    return y, (x, ln, mean, rstd, qkv, o, lse, wqt, wpt, n_w, B, N, heads)
+    return y, (x, ln, mean, rstd, qkv, o, lse, wqt, wpt, (n_w, n_b, qkv_w, qkv_b, proj_w, proj_b), B, N, heads)
 
 
 def _self_attn_bwd(g, saved):
-    x, ln, mean, rstd, qkv, o, lse, wqt, wpt, n_w, B, N, heads = saved
+    x, ln, mean, rstd, qkv, o, lse, wqt, wpt, (n_w, n_b, qkv_w, qkv_b, proj_w, proj_b), B, N, heads = saved
     D = x.shape[-1]
     d = D // heads
     gb = _bf16(g)
     d_o = ops.gemm_nt(ops.EPI_BF16, gb, wpt, None)
-    dwp, dbp = _lin_grads(gb, o)
+    dwp, dbp = _lin_grads(gb, o, proj_w, proj_b)
     dqkv = torch.empty_like(qkv)
     ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, d_o, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
                  B, heads, N, N, d, d ** -0.5)
     dln = ops.gemm_nt(ops.EPI_BF16, dqkv, wqt, None)
-    dwq, dbq = _lin_grads(dqkv, ln)
-    dx, _, dnw, dnb = ops.layernorm_bwd(dln, x, n_w, mean, rstd, dres=g)
+    dwq, dbq = _lin_grads(dqkv, ln, qkv_w, qkv_b)
+    dx, dnw, dnb = _ln_bwd(dln, x, n_w, n_b, mean, rstd, dres=g)
     return dx, [dnw, dnb, dwq, dbq, dwp, dbp]
 
 
@@ -205,14 +238,16 @@ class DecoderHeadFn(torch.autograd.Function):
         o, lse = ops.attn_fwd(q, kv[:, :Dd], kv[:, Dd:], B, heads, ntok, seq, d, d ** -0.5)
         x = ops.gemm_nt(ops.EPI_F32, o, wpr, pr_b)  # the cross-attention output replaces the queries (no residual)
         y, s_mlp = _mlp_fwd(x, on_w, on_b, f1w, f1b, f2w, f2b)
-        ctx.saved = (s_mlp, o, lse, q, kv, qn, cn, queries, context, qmean, qrstd, cmean, crstd, qn_w, cn_w, enc_b,
-                     wqt, wkvt, wprt, wpct, keep32, restore32, meta, (B, seq, D, Dd), len(task_embs))
+        ctx.saved = (s_mlp, o, lse, q, kv, qn, cn, queries, context, qmean, qrstd, cmean, crstd, enc_b,
+                     wqt, wkvt, wprt, wpct, keep32, restore32, meta, (B, seq, D, Dd), [e is not None for e in task_embs],
+                     (pc_w, pc_b, qn_w, qn_b, cn_w, cn_b, q_w, q_b, kv_w, kv_b, pr_w, pr_b))
         return y.reshape(B, ntok, Dd)
 
     @staticmethod
     def backward(ctx, g):
-        (s_mlp, o, lse, q, kv, qn, cn, queries, context, qmean, qrstd, cmean, crstd, qn_w, cn_w, enc_b,
-         wqt, wkvt, wprt, wpct, keep32, restore32, meta, dims, n_task) = ctx.saved
+        (s_mlp, o, lse, q, kv, qn, cn, queries, context, qmean, qrstd, cmean, crstd, enc_b,
+         wqt, wkvt, wprt, wpct, keep32, restore32, meta, dims, task_present,
+         (pc_w, pc_b, qn_w, qn_b, cn_w, cn_b, q_w, q_b, kv_w, kv_b, pr_w, pr_b)) = ctx.saved
         ctx.saved = None
         heads, k, G, T, ntok, q_start = meta
         B, seq, D, Dd = dims
@@ -220,24 +255,24 @@ class DecoderHeadFn(torch.autograd.Function):
         dx, g_mlp = _mlp_bwd(g.contiguous().reshape(B * ntok, Dd), s_mlp)
         dxb = _bf16(dx)
         d_o = ops.gemm_nt(ops.EPI_BF16, dxb, wprt, None)
-        dwpr, dbpr = _lin_grads(dxb, o)
+        dwpr, dbpr = _lin_grads(dxb, o, pr_w, pr_b)
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         ops.attn_bwd(q, kv[:, :Dd], kv[:, Dd:], o, d_o, lse, dq, dkv[:, :Dd], dkv[:, Dd:], B, heads, ntok, seq, d, d ** -0.5)
         dqn = ops.gemm_nt(ops.EPI_BF16, dq, wqt, None)
-        dwq, dbq = _lin_grads(dq, qn)
+        dwq, dbq = _lin_grads(dq, qn, q_w, q_b)
         dcn = ops.gemm_nt(ops.EPI_BF16, dkv, wkvt, None)
-        dwkv, dbkv = _lin_grads(dkv, cn)
-        d_queries, _, dqnw, dqnb = ops.layernorm_bwd(dqn, queries.reshape(B * ntok, Dd), qn_w, qmean, qrstd)
-        d_context, _, dcnw, dcnb = ops.layernorm_bwd(dcn, context.reshape(B * seq, Dd), cn_w, cmean, crstd)
+        dwkv, dbkv = _lin_grads(dkv, cn, kv_w, kv_b)
+        d_queries, dqnw, dqnb = _ln_bwd(dqn, queries.reshape(B * ntok, Dd), qn_w, qn_b, qmean, qrstd)
+        d_context, dcnw, dcnb = _ln_bwd(dcn, context.reshape(B * seq, Dd), cn_w, cn_b, cmean, crstd)
         d_ctx, d_mask, d_task = ops.decoder_assemble_bwd(d_queries.reshape(B, ntok, Dd), d_context.reshape(B, seq, Dd), keep32,
                                                          restore32, k, G, T, ntok, q_start, ntok)
         d_ctx2 = d_ctx.reshape(B * seq, Dd)
         d_enc = ops.gemm_nt(ops.EPI_F32, d_ctx2, wpct, None).reshape(B, seq, D)
-        dwpc, dbpc = _lin_grads(d_ctx2, enc_b)
+        dwpc, dbpc = _lin_grads(d_ctx2, enc_b, pc_w, pc_b)
         dnw, dnb, df1w, df1b, df2w, df2b = g_mlp
         return (d_enc, None, None, None, None, d_mask, dwpc, dbpc, dqnw, dqnb, dcnw, dcnb, dwq, dbq, dwkv, dbkv, dwpr, dbpr,
-                dnw, dnb, df1w, df1b, df2w, df2b, *d_task[:n_task])
+                dnw, dnb, df1w, df1b, df2w, df2b, *[d if present else None for d, present in zip(d_task, task_present)])
 
 
 class OutProjFn(torch.autograd.Function):
@@ -249,16 +284,16 @@ class OutProjFn(torch.autograd.Function):
         xb = ops.cast_bf16(x.contiguous().reshape(B * ntok, Dd))
         wb, wt = bf16_weights(w)
         img = ops.unpatchify_gemm(xb, wb, b, B, C_, P, NH, NW)
-        ctx.saved = (xb, wt, (B, ntok, Dd, P))
+        ctx.saved = (xb, wt, (B, ntok, Dd, P), (w, b))
         return img
 
     @staticmethod
     def backward(ctx, dimg):
-        xb, wt, (B, ntok, Dd, P) = ctx.saved
+        xb, wt, (B, ntok, Dd, P), (w, b) = ctx.saved
         ctx.saved = None
         rows = ops.patchify_bf16(_bf16(dimg.contiguous()), P)
         dx = ops.gemm_nt(ops.EPI_F32, rows, wt, None).reshape(B, ntok, Dd)
-        dw, db = _lin_grads(rows, xb)
+        dw, db = _lin_grads(rows, xb, w, b)
         return dx, dw, db, None, None, None, None
 
 

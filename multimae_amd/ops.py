@@ -107,8 +107,10 @@ def gemm_nt(epi: int, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Ten
     return (out, out2) if epi == EPI_GELU else out
 
 
-def gemm_tn(x: torch.Tensor, y: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False):
-    """out[N,K] (f32) (+)= x[M,N]^T @ y[M,K]."""
+def gemm_tn(x: torch.Tensor, y: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False,
+            colsum_out=None, colsum_accumulate: bool = False):
+    """out[N,K] (f32) (+)= x[M,N]^T @ y[M,K]. colsum_out: True -> also return the column sums of x (f32 [N]); a tensor ->
+    write (or accumulate) them there. Returns out, or (out, colsum) when column sums were requested."""
     _req(x, BF16, "gemm_tn x", contiguous=False)
     _req(y, BF16, "gemm_tn y", contiguous=False)
     M, N, ldx = _rows2d(x, "gemm_tn x")
@@ -120,12 +122,22 @@ def gemm_tn(x: torch.Tensor, y: torch.Tensor, out: Optional[torch.Tensor] = None
         accumulate = False
     else:
         _req(out, F32, "gemm_tn out")
+        if out.numel() != N * K:
+            raise _lib.MmaeError(f"gemm_tn: out has {out.numel()} elements, expected {N}x{K}")
+    cs = None
+    if colsum_out is True:
+        cs = torch.empty((N,), dtype=F32, device=x.device)
+        colsum_accumulate = False
+    elif colsum_out is not None and colsum_out is not False:
+        cs = _req(colsum_out, F32, "gemm_tn colsum_out")
+        if cs.numel() != N:
+            raise _lib.MmaeError(f"gemm_tn: colsum_out has {cs.numel()} elements, expected {N}")
     nbytes = _L().mmae_gemm_tn_workspace_bytes(M, N, K)
     ws = workspace(nbytes, x.device)
     with _Timed("gemm_tn", 2.0 * M * N * K):
-        _lib.check(_L().mmae_gemm_tn(_ptr(x), ldx, _ptr(y), ldy, M, N, K, _ptr(out), int(accumulate), _ptr(ws), ws.numel(),
-                                     _stream()), "gemm_tn")
-    return out
+        _lib.check(_L().mmae_gemm_tn(_ptr(x), ldx, _ptr(y), ldy, M, N, K, _ptr(out), int(accumulate), _ptr(cs),
+                                     int(colsum_accumulate), _ptr(ws), ws.numel(), _stream()), "gemm_tn")
+    return out if cs is None else (out, cs)
 
 
 def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False):
@@ -153,8 +165,8 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
 
 
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
-                  dres: Optional[torch.Tensor] = None, want_bf16: bool = False):
-    """Returns (dx f32 [= dres + LN'(dy)], dx bf16 or None, dgamma, dbeta)."""
+                  dres: Optional[torch.Tensor] = None, want_bf16: bool = False, dgamma=None, dbeta=None):
+    """Returns (dx f32 [= dres + LN'(dy)], dx bf16 or None, dgamma, dbeta); given dgamma / dbeta are accumulated into."""
     _req(dy, BF16, "layernorm_bwd dy"); _req(x, F32, "layernorm_bwd x")
     dim = x.shape[-1]
     rows = x.numel() // dim
@@ -162,11 +174,13 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
         _req(dres, F32, "layernorm_bwd dres")
     dx = torch.empty(x.shape, dtype=F32, device=x.device)
     dxb = torch.empty(x.shape, dtype=BF16, device=x.device) if want_bf16 else None
-    dgamma = torch.empty((dim,), dtype=F32, device=x.device)
-    dbeta = torch.empty((dim,), dtype=F32, device=x.device)
+    acc = int(dgamma is not None)
+    if dgamma is None:
+        dgamma = torch.empty((dim,), dtype=F32, device=x.device)
+        dbeta = torch.empty((dim,), dtype=F32, device=x.device)
     ws = workspace(_L().mmae_layernorm_bwd_workspace_bytes(rows, dim), x.device)
     _lib.check(_L().mmae_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(dxb),
-                                       _ptr(dgamma), _ptr(dbeta), 0, rows, dim, _ptr(ws), ws.numel(), _stream()), "layernorm_bwd")
+                                       _ptr(dgamma), _ptr(dbeta), acc, rows, dim, _ptr(ws), ws.numel(), _stream()), "layernorm_bwd")
     return dx, dxb, dgamma, dbeta
 
 

@@ -80,6 +80,7 @@ class FlatParams:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.grads[o:o + p.numel()].view(p.shape)
+                p._mmae_direct = True  # kernels may accumulate this parameter's gradient in place
         Fn.clear_weight_cache()
 
     def zero_grad(self):
@@ -113,7 +114,9 @@ class GradBuckets:
         self.enabled = self.world > 1
         if self.enabled:
             for i, (_, p) in enumerate(flat.named):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                hook = self._make_hook(i)
+                p.register_post_accumulate_grad_hook(hook)      # gradients delivered by autograd
+                p._mmae_ready = (lambda h=hook, q=p: h(q))       # gradients the kernels wrote in place
 
     def _make_hook(self, i):
         def hook(_p):

@@ -87,8 +87,12 @@ def test_gemm_tn(ops, M, N, K):
     assert out.shape == (N, K) and rel_err(out, ref) < FP32_TOL
     out2 = ops.gemm_tn(x, y, out=out.clone(), accumulate=True)
     assert rel_err(out2, 2 * ref) < FP32_TOL
-    again = ops.gemm_tn(x, y)
+    again, cs = ops.gemm_tn(x, y, colsum_out=True)
     assert torch.equal(again, out), "split-M reduction must be bitwise reproducible"
+    assert rel_err(cs, x.float().sum(0)) < FP32_TOL, "fused column sums (bias gradient)"
+    acc = cs.clone()
+    ops.gemm_tn(x, y, out=out2, accumulate=True, colsum_out=acc, colsum_accumulate=True)
+    assert rel_err(acc, 2 * x.float().sum(0)) < FP32_TOL and rel_err(out2, 3 * ref) < FP32_TOL
 
 
 def test_gemm_tn_asymmetric(ops):
