@@ -45,7 +45,7 @@ int mmae_version(void);
  *   epi 2  out(f32)  = aux(f32) + acc + bias                    (attn.proj / Mlp.fc2 + residual, :283-284)
  *   epi 3  out(bf16) = acc * gelu_erf'(aux(bf16))               (backward through nn.GELU)
  *   epi 4  out(f32)  = acc + bias
- * K must be a multiple of 8, N of 4; bias may be NULL for epi 0/3/4. */
+ * K and N must be multiples of 8; bias may be NULL for epi 0/3/4. */
 int mmae_gemm_nt(int epi, const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,
                  void* out, long ldo, void* out2, const void* aux, long ldaux, mmae_stream_t stream);
 

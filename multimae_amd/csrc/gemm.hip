@@ -54,28 +54,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
     int gm_rows = tiles_m - grp * RASTER_M; gm_rows = gm_rows < RASTER_M ? gm_rows : RASTER_M;
     const int m0 = (grp * RASTER_M + within % gm_rows) * BM, n0 = (within / gm_rows) * BN;
 
-    // staging: wave-instruction j of this wave fills LDS rows (j*4+wave)*8 .. +7 (8 lanes per 128-B row)
+    // staging: wave-instruction j of this wave fills LDS rows (j*4+wave)*8 .. +7 (8 lanes per 128-B row).
+    // LDS holds 16-B chunk c of row r at position c ^ swz(r); swz differs for the two tiles because their fragment
+    // reads walk rows differently (see the fragment row maps below); both make every ds_read_b128 conflict-free.
     const bf16* a_src[4];
     const bf16* w_src[4];
-    int k_src[4];
+    int ka_src[4], kw_src[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = (j * 4 + wave) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);  // source chunk so that LDS holds chunk^swz linearly
+        const int ca = (lane & 7) ^ ((r >> 1) & 7);
+        const int cw = (lane & 7) ^ (((r >> 1) & 1) | (((r >> 3) & 3) << 1));
         int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
         int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
-        a_src[j] = p.A + (long)gm * p.lda + c * 8;
-        w_src[j] = p.W + (long)gn * p.ldw + c * 8;
-        k_src[j] = c * 8;
+        a_src[j] = p.A + (long)gm * p.lda + ca * 8;
+        w_src[j] = p.W + (long)gn * p.ldw + cw * 8;
+        ka_src[j] = ca * 8;
+        kw_src[j] = cw * 8;
     }
     auto stage = [&](int buf, int kt) {
         char* sa = smem + buf * 2 * TILE_BYTES;
         char* sw = sa + TILE_BYTES;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bool in_k = kt * BKT + k_src[j] < p.K;  // chunks past K read zeros (K need not be a multiple of 64)
-            const void* as = in_k ? (const void*)(a_src[j] + kt * BKT) : (const void*)g_zero_page;
-            const void* ws = in_k ? (const void*)(w_src[j] + kt * BKT) : (const void*)g_zero_page;
+            // chunks past K read zeros (K need not be a multiple of 64)
+            const void* as = kt * BKT + ka_src[j] < p.K ? (const void*)(a_src[j] + kt * BKT) : (const void*)g_zero_page;
+            const void* ws = kt * BKT + kw_src[j] < p.K ? (const void*)(w_src[j] + kt * BKT) : (const void*)g_zero_page;
             glds16(as, sa + (j * 4 + wave) * 1024);
             glds16(ws, sw + (j * 4 + wave) * 1024);
         }
@@ -89,7 +93,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
 
     const int nk = (p.K + BKT - 1) / BKT;
     const int fr = lane & 15, fq = lane >> 4;
-    const int swz = fr >> 1;  // (row>>1)&7 with row = 16*t + fr
+    const int swz = fr >> 1;  // both swizzles reduce to fr >> 1 for the rows this lane reads
+    // Fragment row maps.  Activation tile (MFMA B operand, output column m): row = 16*t + fr.
+    // Weight tile (MFMA A operand, output row n): fragments 2u and 2u+1 interleave their rows in groups of four,
+    // row = 32*u + 8*(fr>>2) + 4*(t&1) + (fr&3), so that the accumulators acc[2u][.] and acc[2u+1][.] of a lane are
+    // 8 consecutive output columns n = 32*u + 8*fq + 0..7 (one 16-byte bf16 store / two 16-byte fp32 stores).
+    const int wrow = wn * 64 + 8 * (fr >> 2) + (fr & 3);
     stage(0, 0);
     __syncthreads();
     int cur = 0;
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
             bf16x8 wf[4], af[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                wf[t] = *(const bf16x8*)(sw + (wn * 64 + t * 16 + fr) * 128 + chunk);
+                wf[t] = *(const bf16x8*)(sw + (wrow + 32 * (t >> 1) + 4 * (t & 1)) * 128 + chunk);
                 af[t] = *(const bf16x8*)(sa + (wm * 64 + t * 16 + fr) * 128 + chunk);
             }
 #pragma unroll
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
         cur ^= 1;
     }
 
-    // epilogue: acc[ni][mi][r] = C[m = m0+wm*64+mi*16+fr][n = n0+wn*64+ni*16+fq*4+r]
+    // epilogue: (acc[2u][mi], acc[2u+1][mi]) = C[m = m0+wm*64+mi*16+fr][n = n0+wn*64+32*u+8*fq + 0..7]
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wm * 64 + mi * 16 + fr;
@@ -135,42 +144,57 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
             inh = t / p.NW; inw = t - inh * p.NW;
         }
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 64 + ni * 16 + fq * 4;
+        for (int u = 0; u < 2; ++u) {
+            const int n = n0 + wn * 64 + 32 * u + 8 * fq;
             if (n >= p.N) continue;
-            f32x4 v = acc[ni][mi];
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = acc[2 * u][mi][e]; v[4 + e] = acc[2 * u + 1][mi][e]; }
             if (EPI != EPI_DGELU && EPI != EPI_TOKENS && p.bias) {
-                const f32x4 b = *(const f32x4*)(p.bias + n);
-                v += b;
+                const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
             }
             if (EPI == EPI_BF16) {
-                bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                *(bf16x4*)((bf16*)p.out + orow * p.ldo + n) = o;
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                *(bf16x8*)((bf16*)p.out + orow * p.ldo + n) = o;
             } else if (EPI == EPI_GELU) {
-                bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                bf16x4 g = {(bf16)gelu_erf((float)h[0]), (bf16)gelu_erf((float)h[1]),
-                            (bf16)gelu_erf((float)h[2]), (bf16)gelu_erf((float)h[3])};
-                *(bf16x4*)((bf16*)p.out + orow * p.ldo + n) = h;
-                *(bf16x4*)((bf16*)p.out2 + orow * p.ldo + n) = g;
+                bf16x8 h, g;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { h[e] = (bf16)v[e]; g[e] = (bf16)gelu_erf((float)h[e]); }
+                *(bf16x8*)((bf16*)p.out + orow * p.ldo + n) = h;
+                *(bf16x8*)((bf16*)p.out2 + orow * p.ldo + n) = g;
             } else if (EPI == EPI_RESID) {
-                const f32x4 r = *(const f32x4*)((const float*)p.aux + orow * p.ldaux + n);
-                *(f32x4*)((float*)p.out + orow * p.ldo + n) = r + v;
+                const float* rp = (const float*)p.aux + orow * p.ldaux + n;
+                const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+                float* op = (float*)p.out + orow * p.ldo + n;
+                *(f32x4*)op = (f32x4){r0[0] + v[0], r0[1] + v[1], r0[2] + v[2], r0[3] + v[3]};
+                *(f32x4*)(op + 4) = (f32x4){r1[0] + v[4], r1[1] + v[5], r1[2] + v[6], r1[3] + v[7]};
             } else if (EPI == EPI_DGELU) {
-                const bf16x4 h = *(const bf16x4*)((const bf16*)p.aux + orow * p.ldaux + n);
-                bf16x4 o = {(bf16)(v[0] * gelu_erf_grad((float)h[0])), (bf16)(v[1] * gelu_erf_grad((float)h[1])),
-                            (bf16)(v[2] * gelu_erf_grad((float)h[2])), (bf16)(v[3] * gelu_erf_grad((float)h[3]))};
-                *(bf16x4*)((bf16*)p.out + orow * p.ldo + n) = o;
+                const bf16x8 h = *(const bf16x8*)((const bf16*)p.aux + orow * p.ldaux + n);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)(v[e] * gelu_erf_grad((float)h[e]));
+                *(bf16x8*)((bf16*)p.out + orow * p.ldo + n) = o;
             } else if (EPI == EPI_F32) {
-                *(f32x4*)((float*)p.out + orow * p.ldo + n) = v;
+                float* op = (float*)p.out + orow * p.ldo + n;
+                *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
+                *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
             } else if (EPI == EPI_TOKENS) {
-                const f32x4 t = *(const f32x4*)(tab + n);
-                *(f32x4*)((float*)p.out + orow * p.ldo + n) = v + t;
+                const f32x4 t0 = *(const f32x4*)(tab + n), t1 = *(const f32x4*)(tab + n + 4);
+                float* op = (float*)p.out + orow * p.ldo + n;
+                *(f32x4*)op = (f32x4){v[0] + t0[0], v[1] + t0[1], v[2] + t0[2], v[3] + t0[3]};
+                *(f32x4*)(op + 4) = (f32x4){v[4] + t1[0], v[5] + t1[1], v[6] + t1[2], v[7] + t1[3]};
             } else if (EPI == EPI_UNPATCH) {
                 const int pp = p.P * p.P;
                 const int c = n / pp, rem = n - c * pp, ph = rem / p.P, pw = rem - ph * p.P;
                 const long H = (long)p.NH * p.P, Wd = (long)p.NW * p.P;
-                bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                *(bf16x4*)((bf16*)p.out + (((long)ib * p.C + c) * H + inh * p.P + ph) * Wd + inw * p.P + pw) = o;
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                *(bf16x8*)((bf16*)p.out + (((long)ib * p.C + c) * H + inh * p.P + ph) * Wd + inw * p.P + pw) = o;
             }
         }
     }
@@ -188,7 +212,7 @@ static int check_nt(const void* A, long lda, const void* W, long ldw, int M, int
     MMAE_REQUIRE(A && W && out, MMAE_EINVAL, "gemm_nt: null pointer");
     MMAE_REQUIRE(M > 0 && N > 0 && K > 0, MMAE_EINVAL, "gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
     MMAE_REQUIRE(K % 8 == 0, MMAE_ESHAPE, "gemm_nt: K=%d must be a multiple of 8", K);
-    MMAE_REQUIRE(N % 4 == 0, MMAE_ESHAPE, "gemm_nt: N=%d must be a multiple of 4", N);
+    MMAE_REQUIRE(N % 8 == 0, MMAE_ESHAPE, "gemm_nt: N=%d must be a multiple of 8", N);
     MMAE_REQUIRE(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, MMAE_ESHAPE,
                  "gemm_nt: row strides (lda=%ld, ldw=%ld) must be >= K and multiples of 8", lda, ldw);
     MMAE_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0), MMAE_EINVAL, "gemm_nt: operands must be 16-byte aligned");
@@ -203,7 +227,9 @@ extern "C" int mmae_gemm_nt(int epi, const void* A, long lda, const void* W, lon
     GemmNT p = {};
     p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
     p.bias = bias; p.out = out; p.ldo = ldo; p.out2 = out2; p.aux = aux; p.ldaux = ldaux;
-    MMAE_REQUIRE(ldo >= N && ldo % 4 == 0, MMAE_ESHAPE, "gemm_nt: ldo=%ld must be >= N and a multiple of 4", ldo);
+    MMAE_REQUIRE(ldo >= N && ldo % 8 == 0, MMAE_ESHAPE, "gemm_nt: ldo=%ld must be >= N and a multiple of 8", ldo);
+    MMAE_REQUIRE((uintptr_t)out % 16 == 0 && (!aux || ((uintptr_t)aux % 16 == 0 && ldaux % 8 == 0)) && (!bias || (uintptr_t)bias % 16 == 0),
+                 MMAE_EINVAL, "gemm_nt: out / aux / bias must be 16-byte aligned (aux row stride a multiple of 8)");
     switch (epi) {
         case EPI_BF16: return launch_nt<EPI_BF16>(p, stream);
         case EPI_GELU:
@@ -238,7 +264,7 @@ extern "C" int mmae_unpatchify_gemm(const void* A, long lda, const void* W, int 
                                     void* out_image, int C, int P, int NH, int NW, hipStream_t stream) {
     int rc = check_nt(A, lda, W, K, M, N, K, out_image);
     if (rc) return rc;
-    MMAE_REQUIRE(N == C * P * P && P % 4 == 0 && M % (NH * NW) == 0, MMAE_ESHAPE,
+    MMAE_REQUIRE(N == C * P * P && P % 8 == 0 && M % (NH * NW) == 0, MMAE_ESHAPE,
                  "unpatchify_gemm: N=%d must equal C*P*P (C=%d P=%d) and M=%d a multiple of NH*NW", N, C, P, M);
     GemmNT p = {};
     p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = K; p.M = M; p.N = N; p.K = K;
@@ -399,8 +425,10 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab, i
 
 static int tn_splits(int M, int N, int K) {
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-    int s = (640 + tiles - 1) / tiles;           // aim for ~2.5 workgroups per CU
-    const int max_s = (M + 4 * TN_ROWS - 1) / (4 * TN_ROWS);  // at least 256 rows per split
+    // One resident round: 256 CUs x 2 workgroups of this kernel fit at once; a grid a little over that would run a
+    // second, nearly empty round (576 workgroups took as long as 1024), so split M only as far as tiles * s <= 512.
+    int s = 512 / tiles;
+    const int max_s = (M + 16 * TN_ROWS - 1) / (16 * TN_ROWS);  // at least 1024 rows per split: slab traffic stays small
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
     return s;
