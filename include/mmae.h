@@ -49,6 +49,10 @@ int mmae_version(void);
 int mmae_gemm_nt(int epi, const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,
                  void* out, long ldo, void* out2, const void* aux, long ldaux, mmae_stream_t stream);
 
+/* Kernel choice for mmae_gemm_nt and its two siblings below: 0 = by problem size (default), 1 = always the 128x128
+ * two-workgroups-per-CU kernel, 2 = always the persistent 256x128 kernel.  Process-wide; for tests and tuning. */
+void mmae_gemm_nt_set_variant(int variant);
+
 /* Patch projection of the kept tokens only: out[(m/seg_in)*seg_out + m%seg_in] = A[m] x W^T + add_tab[add_idx[m]]
  * where A holds the packed patches (mmae_pack_patches), W the per-domain Conv2d weights concatenated along K
  * and add_tab = pos_emb + conv bias per (domain, position).  Replaces Conv2d(k=s=P) + rearrange +
@@ -88,14 +92,17 @@ int mmae_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma, 
 /* ---- attention (multimae/multimae_utils.py:200-204 and :240-244) ----------------------------
  * softmax(q k^T * scale) v per (batch, head) without materialising the scores.  q/k/v/o rows are
  * addressed as base + (b*len + i)*ld + h*head_dim, so the packed [B,N,3,H,d] qkv buffer and the
- * [B,M,2,H,d] kv buffer are read in place.  head_dim in {32, 64}; forward: K/V of one head must fit 160 KiB of LDS (kv_len <= 576 at head_dim 64);
- * backward: q_len, kv_len <= 128 at head_dim 64, <= 224 at head_dim 32.
- * fwd also writes lse[B,H,q_len] (f32, natural log) for the backward. */
+ * [B,M,2,H,d] kv buffer are read in place.  head_dim in {32, 64}.  The rows of one head that a kernel keeps in
+ * LDS (K,V for fwd and the dQ kernel; Q,dO for the dK/dV kernel) must fit 160 KiB: <= 568 rows at head_dim 64.
+ * fwd also writes lse[B,H,q_len] (f32, natural log) for the backward.  bwd = two kernels (dQ per query block; dK,dV per
+ * key tile, accumulated in registers: no atomics); workspace holds rowsum(dO*O) [B,H,q_len] f32. */
 int mmae_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
                   float* lse, int B, int H, int q_len, int kv_len, int head_dim, float scale, mmae_stream_t stream);
+size_t mmae_attn_bwd_workspace_bytes(int B, int H, int q_len);
 int mmae_attn_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* o, long ldo,
                   const void* d_o, long lddo, const float* lse, void* dq, long lddq, void* dk, long lddk, void* dv,
-                  long lddv, int B, int H, int q_len, int kv_len, int head_dim, float scale, mmae_stream_t stream);
+                  long lddv, int B, int H, int q_len, int kv_len, int head_dim, float scale, void* workspace,
+                  size_t workspace_bytes, mmae_stream_t stream);
 
 /* ---- masking (multimae/multimae.py:218-253) --------------------------------------------------
  * One workgroup per sample.  task_dist [B,T] f32 is the Dirichlet sample, noise [B,total] f32 the

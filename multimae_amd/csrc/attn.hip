@@ -1,14 +1,14 @@
-// Fused attention for short sequences (whole K/V of one (batch, head) resident in LDS), gfx950.
+// Fused attention for short sequences (whole K/V -- or Q/dO -- of one (batch, head) resident in LDS), gfx950.
 //
-// All MFMAs are v_mfma_f32_32x32x16_bf16 with the KEY (forward, backward phase 1) or the QUERY
-// (backward phase 2) index of the score tile in the accumulator rows, so that a score tile,
-// converted to bf16 in registers, is directly the B operand of the products that reduce over
-// that index (O^T = V^T P^T, dQ^T = K^T dS^T, dV^T = dO^T P, dK^T = Q^T dS): no LDS round trip
-// for P / dS.  The A operands of those products are read from transposed LDS images.
+// All MFMAs are v_mfma_f32_32x32x16_bf16 with the KEY (forward, dQ kernel) or the QUERY (dK/dV kernel) index of the
+// score tile on the accumulator rows, so that a score tile, converted to bf16 in registers, is directly the B operand
+// of the products that reduce over that index (O^T = V^T P^T, dQ^T = K^T dS^T, dV^T = dO^T P, dK^T = Q^T dS): no LDS
+// round trip for P / dS.  The A operands of those products are columns of the row-major LDS images, fetched with the
+// transposing LDS read (ds_read_b64_tr_b16): one image serves both the row reads and the column reads.
 //
 // Accumulator layout of a 32x32 tile: column = lane & 31, row(i) = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5).
-// Registers 8s..8s+7 of a tile, packed to bf16, are k-step s of the next product, whose k slot j of
-// lane half h is tile row 16s + 8(j>>2) + 4h + (j&3); the A operand is fetched in that k order.
+// Registers 8s..8s+7 of a tile, packed to bf16, are k-step s of the next product, whose k slot j of lane half h is
+// tile row 16s + 8(j>>2) + 4h + (j&3); the A operand is fetched in that k order.
 #include "common.h"
 
 #define LOG2E 1.4426950408889634f
@@ -24,6 +24,7 @@ struct AttnArgs {
     bf16* dq; long lddq;
     bf16* dk; long lddk;
     bf16* dv; long lddv;
+    float* delta;  // [B,H,q_len] workspace: rowsum(dO * O), written by the dQ kernel, read by the dK/dV kernel
     int B, H, q_len, kv_len;
     float scale;
 };
@@ -37,21 +38,29 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& t, int s) {
     return r;
 }
 
-// A-operand fragment from a transposed image T[dd][n] (row stride `ld` elements): the 8 k slots of
-// k-step s of tile `nt` for row dd
-__device__ __forceinline__ bf16x8 tr_frag(const bf16* T, int ld, int dd, int n0, int h2) {
-    const bf16x4 lo = *(const bf16x4*)(T + dd * ld + n0 + 4 * h2);
-    const bf16x4 hi = *(const bf16x4*)(T + dd * ld + n0 + 8 + 4 * h2);
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 a;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = 0.f;
+    return a;
+}
+
+// A-operand fragment X^T[dd][n] from the row-major image X[n][ldr]: lane (r = lane & 31 -> column dd0 + r, h2 = lane >> 5)
+// gets rows n0 + 4*h2 + {0..3} and n0 + 8 + 4*h2 + {0..3}.  Each 16-lane group reads a 4-row x 16-column block; lane 4q+p
+// of the group supplies the address of row q, columns 4p..4p+3 and receives column (lane & 15) of the four rows.
+// Needs all 64 lanes active.
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* X, int ldr, int n0, int dd0, int lane) {
+    const int i = lane & 15, h2 = lane >> 5, rhalf = (lane >> 4) & 1;
+    const bf16* p = X + (n0 + 4 * h2 + (i >> 2)) * ldr + dd0 + 16 * rhalf + 4 * (i & 3);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p + 8 * ldr));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// stage rows [0, n_valid) of a [len, D] slice (row stride ld) into a row-major LDS image with padded
-// rows (zero-filled up to n_pad rows) and optionally a transposed image T[D][n_pad + 4].
+// stage rows [0, n_valid) of a [len, D] slice (row stride ld) into a row-major LDS image [n_pad][D + 8], zero-filled tail
 template <int D>
-__device__ __forceinline__ void stage_rows(const bf16* src, long ld, int n_valid, int n_pad, bf16* rowimg, bf16* trimg,
-                                           int tid, int nthreads) {
+__device__ __forceinline__ void stage_rows(const bf16* src, long ld, int n_valid, int n_pad, bf16* img, int tid, int nthreads) {
     constexpr int CH = D / 8, LDR = D + 8;
-    const int ldt = n_pad + 4;
     for (int idx = tid; idx < n_pad * CH; idx += nthreads) {
         const int n = idx / CH, c = idx - n * CH;
         bf16x8 v;
@@ -60,29 +69,26 @@ __device__ __forceinline__ void stage_rows(const bf16* src, long ld, int n_valid
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
         }
-        if (rowimg) *(bf16x8*)(rowimg + n * LDR + c * 8) = v;
-        if (trimg) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) trimg[(c * 8 + e) * ldt + n] = v[e];
-        }
+        *(bf16x8*)(img + n * LDR + c * 8) = v;
     }
 }
 
+// row fragment (A or B operand with the row index on the lane) of a row-major image
+template <int D>
+__device__ __forceinline__ bf16x8 row_frag(const bf16* X, int row, int ks, int h2) {
+    return *(const bf16x8*)(X + row * (D + 8) + ks * 16 + h2 * 8);
+}
+
 // --------------------------------------------------------------------------------------------
-// forward: two passes over the key tiles per 32-query block (row maximum first, then exp / P V), so only
-// one score tile is live at a time; the second Q K^T costs D/16 MFMAs per tile.
+// forward: two passes over the key tiles per 32-query block (row maximum first, then exp / P V), so only one score
+// tile is live at a time; the second Q K^T costs D/16 MFMAs per tile.
 // --------------------------------------------------------------------------------------------
 template <int D>
 __device__ __forceinline__ f32x16 score_tile(const bf16* Ks, int kt, int r, int h2, const bf16x8* qf) {
-    constexpr int LDR = D + 8, KS = D / 16;
-    f32x16 a;
+    f32x16 a = zero16();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(Ks + (kt * 32 + r) * LDR + ks * 16 + h2 * 8);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], a, 0, 0, 0);
-    }
+    for (int ks = 0; ks < D / 16; ++ks)
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Ks, kt * 32 + r, ks, h2), qf[ks], a, 0, 0, 0);
     return a;
 }
 
@@ -90,15 +96,14 @@ template <int D, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p, int nkp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LDR = D + 8, KS = D / 16, DT = D / 32;
-    const int LDT = nkp + 4;
-    bf16* Ks = (bf16*)smem;                 // [nkp][LDR]
-    bf16* Vt = Ks + nkp * LDR;              // [D][LDT]
+    bf16* Ks = (bf16*)smem;     // [nkp][LDR]
+    bf16* Vs = Ks + nkp * LDR;  // [nkp][LDR]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h2 = lane >> 5;
     const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
 
-    stage_rows<D>(p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.kv_len, nkp, Ks, nullptr, tid, NW * 64);
-    stage_rows<D>(p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.kv_len, nkp, nullptr, Vt, tid, NW * 64);
+    stage_rows<D>(p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.kv_len, nkp, Ks, tid, NW * 64);
+    stage_rows<D>(p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.kv_len, nkp, Vs, tid, NW * 64);
     __syncthreads();
 
     const float c = p.scale * LOG2E;
@@ -124,15 +129,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p, int nkp) 
         float l = 0.f;
         f32x16 oacc[DT];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[dt][i] = 0.f;
+        for (int dt = 0; dt < DT; ++dt) oacc[dt] = zero16();
         for (int kt = 0; kt < nkt; ++kt) {
             f32x16 a = score_tile<D>(Ks, kt, r, h2, qf);
             const int lim = kt == nkt - 1 ? tail : 32;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float e = acc_row(i, h2) < lim ? exp2f((a[i] - m) * c) : 0.f;
+                const float e = acc_row(i, h2) < lim ? __builtin_amdgcn_exp2f((a[i] - m) * c) : 0.f;
                 a[i] = e;
                 l += e;
             }
@@ -140,10 +143,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p, int nkp) 
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 pf = pack8(a, s2);
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    const bf16x8 vf = tr_frag(Vt, LDT, dt * 32 + r, kt * 32 + 16 * s2, h2);
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
-                }
+                for (int dt = 0; dt < DT; ++dt)
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vs, LDR, kt * 32 + 16 * s2, dt * 32, lane), pf, oacc[dt], 0, 0, 0);
             }
         }
         l += __shfl_xor(l, 32, 64);
@@ -165,105 +166,72 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p, int nkp) 
 }
 
 // --------------------------------------------------------------------------------------------
-// backward: phase 1 per 32-query block (dQ), phase 2 per 32-key tile (dK, dV); P is recomputed
-// from the forward's log-sum-exp, delta = rowsum(dO * O).
+// backward, kernel 1: dQ per 32-query block.  K and V of the head live in LDS; Q, dO, O rows come straight from
+// global memory as fragments.  P is recomputed from the forward's log-sum-exp; delta = rowsum(dO * O) is computed from
+// the fragments and also written out for kernel 2.
 // --------------------------------------------------------------------------------------------
-template <int D, int NQT, int NKT>
-struct BwdLds {
-    static constexpr int LDR = D + 8, NQP = NQT * 32, NKP = NKT * 32, LDTQ = NQP + 4, LDTK = NKP + 4;
-    static constexpr size_t bytes =
-        sizeof(bf16) * (size_t)(2 * NQP * LDR + 2 * NKP * LDR + D * LDTK + 2 * D * LDTQ) + sizeof(float) * 2 * NQP;
-};
-
-template <int D, int NQT, int NKT, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(AttnArgs p) {
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs p, int nkp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using L = BwdLds<D, NQT, NKT>;
-    constexpr int LDR = L::LDR, NQP = L::NQP, NKP = L::NKP, LDTQ = L::LDTQ, LDTK = L::LDTK, KS = D / 16, DT = D / 32, CH = D / 8;
-    bf16* Qs = (bf16*)smem;            // [NQP][LDR]
-    bf16* dOs = Qs + NQP * LDR;        // [NQP][LDR]
-    bf16* Ks = dOs + NQP * LDR;        // [NKP][LDR]
-    bf16* Vs = Ks + NKP * LDR;         // [NKP][LDR]
-    bf16* Kt = Vs + NKP * LDR;         // [D][LDTK]
-    bf16* Qt = Kt + D * LDTK;          // [D][LDTQ]
-    bf16* dOt = Qt + D * LDTQ;         // [D][LDTQ]
-    float* lse2 = (float*)(dOt + D * LDTQ);  // [NQP]
-    float* delta = lse2 + NQP;               // [NQP]
+    constexpr int LDR = D + 8, KS = D / 16, DT = D / 32;
+    bf16* Ks = (bf16*)smem;
+    bf16* Vs = Ks + nkp * LDR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h2 = lane >> 5;
     const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
-    constexpr int NT = NW * 64;
 
-    stage_rows<D>(p.q + (long)b * p.q_len * p.ldq + h * D, p.ldq, p.q_len, NQP, Qs, Qt, tid, NT);
-    stage_rows<D>(p.dO + (long)b * p.q_len * p.lddo + h * D, p.lddo, p.q_len, NQP, dOs, dOt, tid, NT);
-    stage_rows<D>(p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.kv_len, NKP, Ks, Kt, tid, NT);
-    stage_rows<D>(p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.kv_len, NKP, Vs, nullptr, tid, NT);
-    // delta[q] = sum_d dO[q,d] * O[q,d]; CH consecutive threads share a query
-    for (int idx = tid; idx < NQP * CH; idx += NT) {
-        const int n = idx / CH, cc = idx - n * CH;
-        float part = 0.f;
-        if (n < p.q_len) {
-            const bf16x8 a = *(const bf16x8*)(p.dO + ((long)b * p.q_len + n) * p.lddo + h * D + cc * 8);
-            const bf16x8 o = *(const bf16x8*)(p.o + ((long)b * p.q_len + n) * p.ldo + h * D + cc * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) part += (float)a[e] * (float)o[e];
-        }
-#pragma unroll
-        for (int off = 1; off < CH; off <<= 1) part += __shfl_xor(part, off, 64);
-        if (cc == 0) {
-            delta[n] = part;
-            lse2[n] = n < p.q_len ? p.lse[((long)b * p.H + h) * p.q_len + n] * LOG2E : 1e30f;
-        }
-    }
+    stage_rows<D>(p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.kv_len, nkp, Ks, tid, NW * 64);
+    stage_rows<D>(p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.kv_len, nkp, Vs, tid, NW * 64);
     __syncthreads();
 
     const float c = p.scale * LOG2E;
-    const int nqt = (p.q_len + 31) / 32, nkt = (p.kv_len + 31) / 32;
+    const int nqt = (p.q_len + 31) / 32, nkt = nkp / 32;
     const int tail = p.kv_len - (nkt - 1) * 32;
-
-    // ---- phase 1: dQ ---------------------------------------------------------------------
     for (int qb = wave; qb < nqt; qb += NW) {
+        const int qrow = qb * 32 + r;
+        const bool qvalid = qrow < p.q_len;
+        const int qc = qvalid ? qrow : p.q_len - 1;
+        const long rowoff = (long)b * p.q_len + qc;
         bf16x8 qf[KS], dof[KS];
+        float dpart = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qf[ks] = *(const bf16x8*)(Qs + (qb * 32 + r) * LDR + ks * 16 + h2 * 8);
-            dof[ks] = *(const bf16x8*)(dOs + (qb * 32 + r) * LDR + ks * 16 + h2 * 8);
+            qf[ks] = *(const bf16x8*)(p.q + rowoff * p.ldq + h * D + h2 * 8 + ks * 16);
+            dof[ks] = *(const bf16x8*)(p.dO + rowoff * p.lddo + h * D + h2 * 8 + ks * 16);
+            const bf16x8 of = *(const bf16x8*)(p.o + rowoff * p.ldo + h * D + h2 * 8 + ks * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dpart += (float)dof[ks][e] * (float)of[e];
         }
-        const float my_lse = lse2[qb * 32 + r], my_delta = delta[qb * 32 + r];
+        const float my_delta = dpart + __shfl_xor(dpart, 32, 64);
+        // padded query rows: lse = +big makes every recomputed probability 0
+        const float my_lse = qvalid ? p.lse[((long)b * p.H + h) * p.q_len + qrow] * LOG2E : 1e30f;
+        if (h2 == 0 && qvalid) p.delta[((long)b * p.H + h) * p.q_len + qrow] = my_delta;
+
         f32x16 dq[DT];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) dq[dt][i] = 0.f;
+        for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
         for (int kt = 0; kt < nkt; ++kt) {
-            f32x16 s, dp;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+            f32x16 s = zero16(), dp = zero16();
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(Ks + (kt * 32 + r) * LDR + ks * 16 + h2 * 8);
-                const bf16x8 vf = *(const bf16x8*)(Vs + (kt * 32 + r) * LDR + ks * 16 + h2 * 8);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Ks, kt * 32 + r, ks, h2), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vs, kt * 32 + r, ks, h2), dof[ks], dp, 0, 0, 0);
             }
+            const int lim = kt == nkt - 1 ? tail : 32;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const bool valid = acc_row(i, h2) < (kt == nkt - 1 ? tail : 32);
-                const float pr = valid ? exp2f(s[i] * c - my_lse) : 0.f;
+                const float pr = acc_row(i, h2) < lim ? __builtin_amdgcn_exp2f(s[i] * c - my_lse) : 0.f;
                 s[i] = pr * (dp[i] - my_delta) * p.scale;
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 dsf = pack8(s, s2);
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    const bf16x8 ktf = tr_frag(Kt, LDTK, dt * 32 + r, kt * 32 + 16 * s2, h2);
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq[dt], 0, 0, 0);
-                }
+                for (int dt = 0; dt < DT; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ks, LDR, kt * 32 + 16 * s2, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
             }
         }
-        const int qrow = qb * 32 + r;
-        if (qrow < p.q_len) {
+        if (qvalid) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 bf16* op = p.dq + ((long)b * p.q_len + qrow) * p.lddq + h * D + dt * 32 + 4 * h2;
@@ -275,31 +243,54 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(AttnArgs p) {
             }
         }
     }
+}
 
-    // ---- phase 2: dK, dV -------------------------------------------------------------------
+// --------------------------------------------------------------------------------------------
+// backward, kernel 2: dK, dV per 32-key tile.  Q and dO of the head live in LDS (+ lse, delta per query); the K and V
+// rows of the tile come from global memory as fragments; accumulation over the query blocks stays in registers.
+// --------------------------------------------------------------------------------------------
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs p, int nqp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LDR = D + 8, KS = D / 16, DT = D / 32;
+    bf16* Qs = (bf16*)smem;                    // [nqp][LDR]
+    bf16* dOs = Qs + nqp * LDR;                // [nqp][LDR]
+    float* lse2 = (float*)(dOs + nqp * LDR);   // [nqp]
+    float* delta = lse2 + nqp;                 // [nqp]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h2 = lane >> 5;
+    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+
+    stage_rows<D>(p.q + (long)b * p.q_len * p.ldq + h * D, p.ldq, p.q_len, nqp, Qs, tid, NW * 64);
+    stage_rows<D>(p.dO + (long)b * p.q_len * p.lddo + h * D, p.lddo, p.q_len, nqp, dOs, tid, NW * 64);
+    for (int n = tid; n < nqp; n += NW * 64) {
+        const bool ok = n < p.q_len;
+        lse2[n] = ok ? p.lse[((long)b * p.H + h) * p.q_len + n] * LOG2E : 1e30f;
+        delta[n] = ok ? p.delta[((long)b * p.H + h) * p.q_len + n] : 0.f;
+    }
+    __syncthreads();
+
+    const float c = p.scale * LOG2E;
+    const int nqt = nqp / 32, nkt = (p.kv_len + 31) / 32;
     for (int kt = wave; kt < nkt; kt += NW) {
+        const int key = kt * 32 + r;
+        const bool key_valid = key < p.kv_len;
+        const long krow = (long)b * p.kv_len + (key_valid ? key : p.kv_len - 1);
         bf16x8 kf[KS], vf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            kf[ks] = *(const bf16x8*)(Ks + (kt * 32 + r) * LDR + ks * 16 + h2 * 8);
-            vf[ks] = *(const bf16x8*)(Vs + (kt * 32 + r) * LDR + ks * 16 + h2 * 8);
+            kf[ks] = *(const bf16x8*)(p.k + krow * p.ldk + h * D + h2 * 8 + ks * 16);
+            vf[ks] = *(const bf16x8*)(p.v + krow * p.ldv + h * D + h2 * 8 + ks * 16);
         }
-        const bool key_valid = kt * 32 + r < p.kv_len;
         f32x16 dk[DT], dv[DT];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { dk[dt][i] = 0.f; dv[dt][i] = 0.f; }
+        for (int dt = 0; dt < DT; ++dt) { dk[dt] = zero16(); dv[dt] = zero16(); }
         for (int qb = 0; qb < nqt; ++qb) {
-            f32x16 s, dp;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+            f32x16 s = zero16(), dp = zero16();
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 qa = *(const bf16x8*)(Qs + (qb * 32 + r) * LDR + ks * 16 + h2 * 8);
-                const bf16x8 da = *(const bf16x8*)(dOs + (qb * 32 + r) * LDR + ks * 16 + h2 * 8);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Qs, qb * 32 + r, ks, h2), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(dOs, qb * 32 + r, ks, h2), vf[ks], dp, 0, 0, 0);
             }
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
@@ -308,7 +299,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(AttnArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * i4 + e;
-                    const float pr = key_valid ? exp2f(s[i] * c - lv[e]) : 0.f;
+                    const float pr = key_valid ? __builtin_amdgcn_exp2f(s[i] * c - lv[e]) : 0.f;
                     s[i] = pr;
                     dp[i] = pr * (dp[i] - dl[e]) * p.scale;
                 }
@@ -318,15 +309,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(AttnArgs p) {
                 const bf16x8 pf = pack8(s, s2), dsf = pack8(dp, s2);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const bf16x8 dot = tr_frag(dOt, LDTQ, dt * 32 + r, qb * 32 + 16 * s2, h2);
-                    const bf16x8 qt = tr_frag(Qt, LDTQ, dt * 32 + r, qb * 32 + 16 * s2, h2);
-                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pf, dv[dt], 0, 0, 0);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, dsf, dk[dt], 0, 0, 0);
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dOs, LDR, qb * 32 + 16 * s2, dt * 32, lane), pf, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qs, LDR, qb * 32 + 16 * s2, dt * 32, lane), dsf, dk[dt], 0, 0, 0);
                 }
             }
         }
-        const int key = kt * 32 + r;
-        if (key < p.kv_len) {
+        if (key_valid) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 bf16* kp = p.dk + ((long)b * p.kv_len + key) * p.lddk + h * D + dt * 32 + 4 * h2;
@@ -346,47 +334,45 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(AttnArgs p) {
 // --------------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------------
+#define ATTN_MAX_LDS (160 * 1024)
+
 template <typename K>
-static int set_lds(K kern, size_t bytes) {
-    if (bytes > 65536) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+static int launch_with_lds(K kern, const char* name, size_t bytes, int blocks, int threads, hipStream_t s, const AttnArgs& a, int npad,
+                           bool& reserved) {
+    MMAE_REQUIRE(bytes <= ATTN_MAX_LDS, MMAE_ESHAPE, "%s: sequence needs %zu bytes of LDS (> 160 KiB)", name, bytes);
+    if (bytes > 65536 && !reserved) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_MAX_LDS);
         if (e != hipSuccess) {
-            mmae_set_error("attention: cannot reserve %zu bytes of LDS: %s", bytes, hipGetErrorString(e));
+            mmae_set_error("%s: cannot reserve LDS: %s", name, hipGetErrorString(e));
             return MMAE_ELAUNCH;
         }
+        reserved = true;
     }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), bytes, s, a, npad);
+    MMAE_CHECK_LAUNCH(name);
     return MMAE_OK;
 }
+
+static inline int pad32(int n) { return (n + 31) / 32 * 32; }
 
 template <int D, int NW>
 static int launch_fwd(const AttnArgs& a, hipStream_t s) {
-    const int nkp = (a.kv_len + 31) / 32 * 32;
-    const size_t bytes = sizeof(bf16) * ((size_t)nkp * (D + 8) + (size_t)D * (nkp + 4));
-    MMAE_REQUIRE(bytes <= 160 * 1024, MMAE_ESHAPE, "attn_fwd: kv_len %d needs %zu bytes of LDS (> 160 KiB)", a.kv_len, bytes);
-    static size_t reserved = 0;  // largest dynamic LDS size requested so far for this instantiation
-    if (bytes > 65536 && bytes > reserved) {
-        int rc = set_lds(attn_fwd_kernel<D, NW>, 160 * 1024);
-        if (rc) return rc;
-        reserved = 160 * 1024;
-    }
-    hipLaunchKernelGGL((attn_fwd_kernel<D, NW>), dim3(a.B * a.H), dim3(NW * 64), bytes, s, a, nkp);
-    MMAE_CHECK_LAUNCH("attn_fwd");
-    return MMAE_OK;
-}
-
-template <int D, int NQT, int NKT, int NW>
-static int launch_bwd(const AttnArgs& a, hipStream_t s) {
-    constexpr size_t bytes = BwdLds<D, NQT, NKT>::bytes;
-    static_assert(bytes <= 160 * 1024, "backward LDS image exceeds one CU");
     static bool reserved = false;
-    if (!reserved) {
-        int rc = set_lds(attn_bwd_kernel<D, NQT, NKT, NW>, bytes);
-        if (rc) return rc;
-        reserved = true;
-    }
-    hipLaunchKernelGGL((attn_bwd_kernel<D, NQT, NKT, NW>), dim3(a.B * a.H), dim3(NW * 64), bytes, s, a);
-    MMAE_CHECK_LAUNCH("attn_bwd");
-    return MMAE_OK;
+    const int nkp = pad32(a.kv_len);
+    return launch_with_lds(attn_fwd_kernel<D, NW>, "attn_fwd", sizeof(bf16) * 2 * (size_t)nkp * (D + 8), a.B * a.H, NW * 64, s, a, nkp, reserved);
+}
+template <int D, int NW>
+static int launch_dq(const AttnArgs& a, hipStream_t s) {
+    static bool reserved = false;
+    const int nkp = pad32(a.kv_len);
+    return launch_with_lds(attn_bwd_dq_kernel<D, NW>, "attn_bwd_dq", sizeof(bf16) * 2 * (size_t)nkp * (D + 8), a.B * a.H, NW * 64, s, a, nkp, reserved);
+}
+template <int D, int NW>
+static int launch_dkv(const AttnArgs& a, hipStream_t s) {
+    static bool reserved = false;
+    const int nqp = pad32(a.q_len);
+    return launch_with_lds(attn_bwd_dkv_kernel<D, NW>, "attn_bwd_dkv", sizeof(bf16) * 2 * (size_t)nqp * (D + 8) + sizeof(float) * 2 * nqp,
+                           a.B * a.H, NW * 64, s, a, nqp, reserved);
 }
 
 static int check_common(const AttnArgs& a, int head_dim, const char* who) {
@@ -395,7 +381,7 @@ static int check_common(const AttnArgs& a, int head_dim, const char* who) {
     MMAE_REQUIRE(head_dim == 32 || head_dim == 64, MMAE_ESHAPE, "%s: head_dim %d not in {32, 64}", who, head_dim);
     MMAE_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 8 == 0, MMAE_ESHAPE,
                  "%s: row strides must be multiples of 8 elements", who);
-    MMAE_REQUIRE(((uintptr_t)a.q % 16 == 0) && ((uintptr_t)a.k % 16 == 0) && ((uintptr_t)a.v % 16 == 0) && ((uintptr_t)a.o % 8 == 0),
+    MMAE_REQUIRE(((uintptr_t)a.q % 16 == 0) && ((uintptr_t)a.k % 16 == 0) && ((uintptr_t)a.v % 16 == 0) && ((uintptr_t)a.o % 16 == 0),
                  MMAE_EINVAL, "%s: pointers must be 16-byte aligned", who);
     return MMAE_OK;
 }
@@ -407,32 +393,36 @@ extern "C" int mmae_attn_fwd(const void* q, long ldq, const void* k, long ldk, c
     a.o = (bf16*)o; a.ldo = ldo; a.lse = lse; a.B = B; a.H = H; a.q_len = q_len; a.kv_len = kv_len; a.scale = scale;
     int rc = check_common(a, head_dim, "attn_fwd");
     if (rc) return rc;
-    const int nqt = (q_len + 31) / 32;
-    if (head_dim == 64) return nqt > 4 ? launch_fwd<64, 8>(a, stream) : launch_fwd<64, 4>(a, stream);
-    return nqt > 4 ? launch_fwd<32, 8>(a, stream) : launch_fwd<32, 4>(a, stream);
+    const bool wide = (q_len + 31) / 32 > 4;
+    if (head_dim == 64) return wide ? launch_fwd<64, 8>(a, stream) : launch_fwd<64, 4>(a, stream);
+    return wide ? launch_fwd<32, 8>(a, stream) : launch_fwd<32, 4>(a, stream);
 }
+
+extern "C" size_t mmae_attn_bwd_workspace_bytes(int B, int H, int q_len) { return (size_t)B * H * q_len * sizeof(float); }
 
 extern "C" int mmae_attn_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* o,
                              long ldo, const void* d_o, long lddo, const float* lse, void* dq, long lddq, void* dk, long lddk,
                              void* dv, long lddv, int B, int H, int q_len, int kv_len, int head_dim, float scale,
-                             hipStream_t stream) {
+                             void* workspace, size_t workspace_bytes, hipStream_t stream) {
     AttnArgs a = {};
     a.q = (const bf16*)q; a.ldq = ldq; a.k = (const bf16*)k; a.ldk = ldk; a.v = (const bf16*)v; a.ldv = ldv;
     a.o = (bf16*)o; a.ldo = ldo; a.lse = (float*)lse; a.dO = (const bf16*)d_o; a.lddo = lddo;
     a.dq = (bf16*)dq; a.lddq = lddq; a.dk = (bf16*)dk; a.lddk = lddk; a.dv = (bf16*)dv; a.lddv = lddv;
+    a.delta = (float*)workspace;
     a.B = B; a.H = H; a.q_len = q_len; a.kv_len = kv_len; a.scale = scale;
     int rc = check_common(a, head_dim, "attn_bwd");
     if (rc) return rc;
-    MMAE_REQUIRE(d_o && dq && dk && dv, MMAE_EINVAL, "attn_bwd: null pointer");
-    MMAE_REQUIRE(lddo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, MMAE_ESHAPE, "attn_bwd: bad gradient strides");
-    const int nkt = (kv_len + 31) / 32, nqt = (q_len + 31) / 32;
+    MMAE_REQUIRE(d_o && dq && dk && dv && workspace, MMAE_EINVAL, "attn_bwd: null pointer");
+    MMAE_REQUIRE(workspace_bytes >= mmae_attn_bwd_workspace_bytes(B, H, q_len), MMAE_EWORKSPACE, "attn_bwd: workspace too small");
+    MMAE_REQUIRE(lddo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 && (uintptr_t)d_o % 16 == 0, MMAE_ESHAPE,
+                 "attn_bwd: bad gradient strides / alignment");
+    const bool wide_q = (q_len + 31) / 32 > 4, wide_k = (kv_len + 31) / 32 > 4;
     if (head_dim == 64) {
-        MMAE_REQUIRE(nqt <= 4 && nkt <= 4, MMAE_ESHAPE,
-                     "attn_bwd: head_dim 64 supports q_len, kv_len <= 128 (got %d, %d)", q_len, kv_len);
-        return launch_bwd<64, 4, 4, 4>(a, stream);
+        rc = wide_q ? launch_dq<64, 8>(a, stream) : launch_dq<64, 4>(a, stream);
+        if (rc) return rc;
+        return wide_k ? launch_dkv<64, 8>(a, stream) : launch_dkv<64, 4>(a, stream);
     }
-    MMAE_REQUIRE(nqt <= 7 && nkt <= 7, MMAE_ESHAPE, "attn_bwd: head_dim 32 supports q_len, kv_len <= 224 (got %d, %d)", q_len, kv_len);
-    if (nqt <= 4 && nkt <= 4) return launch_bwd<32, 4, 4, 4>(a, stream);
-    if (nkt <= 4) return launch_bwd<32, 7, 4, 8>(a, stream);
-    return launch_bwd<32, 7, 7, 8>(a, stream);
+    rc = wide_q ? launch_dq<32, 8>(a, stream) : launch_dq<32, 4>(a, stream);
+    if (rc) return rc;
+    return wide_k ? launch_dkv<32, 8>(a, stream) : launch_dkv<32, 4>(a, stream);
 }

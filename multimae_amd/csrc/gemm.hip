@@ -38,6 +38,83 @@ struct GemmNT {
     int C, P, NH, NW;           // EPI_UNPATCH
 };
 
+// Stores one wave's 64x64 accumulator block: (acc[2u][mi], acc[2u+1][mi]) = C[m = mw + mi*16 + fr][n = nw + 32*u + 8*fq + 0..7]
+template <int EPI>
+__device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&acc)[4][4], int mw, int nw, int fr, int fq) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = mw + mi * 16 + fr;
+        if (m >= p.M) continue;
+        long orow = m;
+        const float* tab = nullptr;
+        int ib = 0, inh = 0, inw = 0;
+        if (EPI == EPI_TOKENS) {
+            orow = (long)(m / p.seg_in) * p.seg_out + (m % p.seg_in);
+            tab = p.add_tab + (long)p.add_idx[m] * p.N;
+        }
+        if (EPI == EPI_UNPATCH) {
+            const int ntok = p.NH * p.NW;
+            ib = m / ntok;
+            const int t = m - ib * ntok;
+            inh = t / p.NW; inw = t - inh * p.NW;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int n = nw + 32 * u + 8 * fq;
+            if (n >= p.N) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = acc[2 * u][mi][e]; v[4 + e] = acc[2 * u + 1][mi][e]; }
+            if (EPI != EPI_DGELU && EPI != EPI_TOKENS && p.bias) {
+                const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+            }
+            if (EPI == EPI_BF16) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                *(bf16x8*)((bf16*)p.out + orow * p.ldo + n) = o;
+            } else if (EPI == EPI_GELU) {
+                bf16x8 h, g;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { h[e] = (bf16)v[e]; g[e] = (bf16)gelu_erf((float)h[e]); }
+                *(bf16x8*)((bf16*)p.out + orow * p.ldo + n) = h;
+                *(bf16x8*)((bf16*)p.out2 + orow * p.ldo + n) = g;
+            } else if (EPI == EPI_RESID) {
+                const float* rp = (const float*)p.aux + orow * p.ldaux + n;
+                const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+                float* op = (float*)p.out + orow * p.ldo + n;
+                *(f32x4*)op = (f32x4){r0[0] + v[0], r0[1] + v[1], r0[2] + v[2], r0[3] + v[3]};
+                *(f32x4*)(op + 4) = (f32x4){r1[0] + v[4], r1[1] + v[5], r1[2] + v[6], r1[3] + v[7]};
+            } else if (EPI == EPI_DGELU) {
+                const bf16x8 h = *(const bf16x8*)((const bf16*)p.aux + orow * p.ldaux + n);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)(v[e] * gelu_erf_grad((float)h[e]));
+                *(bf16x8*)((bf16*)p.out + orow * p.ldo + n) = o;
+            } else if (EPI == EPI_F32) {
+                float* op = (float*)p.out + orow * p.ldo + n;
+                *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
+                *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            } else if (EPI == EPI_TOKENS) {
+                const f32x4 t0 = *(const f32x4*)(tab + n), t1 = *(const f32x4*)(tab + n + 4);
+                float* op = (float*)p.out + orow * p.ldo + n;
+                *(f32x4*)op = (f32x4){v[0] + t0[0], v[1] + t0[1], v[2] + t0[2], v[3] + t0[3]};
+                *(f32x4*)(op + 4) = (f32x4){v[4] + t1[0], v[5] + t1[1], v[6] + t1[2], v[7] + t1[3]};
+            } else if (EPI == EPI_UNPATCH) {
+                const int pp = p.P * p.P;
+                const int c = n / pp, rem = n - c * pp, ph = rem / p.P, pw = rem - ph * p.P;
+                const long H = (long)p.NH * p.P, Wd = (long)p.NW * p.P;
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                *(bf16x8*)((bf16*)p.out + (((long)ib * p.C + c) * H + inh * p.P + ph) * Wd + inw * p.P + pw) = o;
+            }
+        }
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
@@ -125,83 +202,325 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
         cur ^= 1;
     }
 
-    // epilogue: (acc[2u][mi], acc[2u+1][mi]) = C[m = m0+wm*64+mi*16+fr][n = n0+wn*64+32*u+8*fq + 0..7]
+    store_wave_tile<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent 256x128 variant for the large problems.  A 128x128 tile moves 1 byte from L2 per 64 FLOP and tops out
+// near 0.9 PFLOP/s on L2 -> LDS bandwidth; 256x128 halves the W traffic per FLOP.  Eight waves (4 x 2, 64x64 each),
+// one workgroup per CU, a 3-stage LDS ring filled two k-tiles ahead by 16-byte LDS-DMA, counted vmcnt + raw
+// s_barrier so the prefetch stays in flight across barriers, and the ring runs on across tile boundaries (the next
+// tile's first k-tiles are already landing while this tile's epilogue stores).
+// ------------------------------------------------------------------------------------------
+#define PBM 256
+#define PSTAGE_BYTES 49152  // A 256x64 bf16 (32 KiB) + W 128x64 bf16 (16 KiB)
+#define PSTAGES 3
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmNT p, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char psmem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4, swz = fr >> 1;
+    const int wrow = wn * 64 + 8 * (fr >> 2) + (fr & 3);
+    const int ntiles = tiles_m * tiles_n, G = gridDim.x;
+    const int me = xcd_remap(blockIdx.x, G);  // workgroups that share an XCD take neighbouring tiles of each round
+    const int nk = (p.K + BKT - 1) / BKT;
+    const int my_tiles = me < ntiles ? (ntiles - 1 - me) / G + 1 : 0;
+    const int total = my_tiles * nk;
+
+    auto tile_origin = [&](int t, int& m0, int& n0) {  // groups of 4 row-tiles x all column-tiles, rows fastest
+        const int per_group = 4 * tiles_n;
+        const int grp = t / per_group, within = t - grp * per_group;
+        int rows = tiles_m - grp * 4; rows = rows < 4 ? rows : 4;
+        m0 = (grp * 4 + within % rows) * PBM;
+        n0 = (within / rows) * BN;
+    };
+
+    // ---- load cursor ----
+    const bf16* a_src[4]; const bf16* w_src[2];
+    int ka_src[4], kw_src[2];
+    int ld_tile = me, ld_kt = 0, ld_it = 0;
+    auto set_sources = [&](int t) {
+        int m0, n0;
+        tile_origin(t, m0, n0);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 64 + mi * 16 + fr;
-        if (m >= p.M) continue;
-        long orow = m;
-        const float* tab = nullptr;
-        int ib = 0, inh = 0, inw = 0;
-        if (EPI == EPI_TOKENS) {
-            orow = (long)(m / p.seg_in) * p.seg_out + (m % p.seg_in);
-            tab = p.add_tab + (long)p.add_idx[m] * p.N;
+        for (int j = 0; j < 4; ++j) {
+            const int r = (j * 8 + wave) * 8 + (lane >> 3);
+            const int ca = (lane & 7) ^ ((r >> 1) & 7);
+            int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
+            a_src[j] = p.A + (long)gm * p.lda + ca * 8;
+            ka_src[j] = ca * 8;
         }
-        if (EPI == EPI_UNPATCH) {
-            const int ntok = p.NH * p.NW;
-            ib = m / ntok;
-            const int t = m - ib * ntok;
-            inh = t / p.NW; inw = t - inh * p.NW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (j * 8 + wave) * 8 + (lane >> 3);
+            const int cw = (lane & 7) ^ (((r >> 1) & 1) | (((r >> 3) & 3) << 1));
+            int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
+            w_src[j] = p.W + (long)gn * p.ldw + cw * 8;
+            kw_src[j] = cw * 8;
+        }
+    };
+    auto issue = [&]() {  // loads of ring iteration ld_it (6 LDS-DMA per thread)
+        char* sa = psmem + (ld_it % PSTAGES) * PSTAGE_BYTES;
+        char* sw = sa + 32768;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const void* as = ld_kt * BKT + ka_src[j] < p.K ? (const void*)(a_src[j] + ld_kt * BKT) : (const void*)g_zero_page;
+            glds16(as, sa + (j * 8 + wave) * 1024);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int n = n0 + wn * 64 + 32 * u + 8 * fq;
-            if (n >= p.N) continue;
-            float v[8];
+        for (int j = 0; j < 2; ++j) {
+            const void* ws = ld_kt * BKT + kw_src[j] < p.K ? (const void*)(w_src[j] + ld_kt * BKT) : (const void*)g_zero_page;
+            glds16(ws, sw + (j * 8 + wave) * 1024);
+        }
+        ++ld_it;
+        if (++ld_kt == nk) {
+            ld_kt = 0;
+            ld_tile += G;
+            if (ld_tile < ntiles) set_sources(ld_tile);
+        }
+    };
+
+    if (total == 0) return;
+    set_sources(ld_tile);
+    issue();
+    if (total > 1) {
+        issue();
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 acc[4][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = acc[2 * u][mi][e]; v[4 + e] = acc[2 * u + 1][mi][e]; }
-            if (EPI != EPI_DGELU && EPI != EPI_TOKENS && p.bias) {
-                const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int tile = me, kt = 0;
+    for (int it = 0; it < total; ++it) {
+        const bool more = ld_it < total;
+        if (more) issue();  // ring iteration it+2 -> stage (it+2) % 3, last read in iteration it-1
+        const char* sa = psmem + (it % PSTAGES) * PSTAGE_BYTES;
+        const char* sw = sa + 32768;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = ((ks * 4 + fq) ^ swz) << 4;
+            bf16x8 wf[4], af[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                wf[t] = *(const bf16x8*)(sw + (wrow + 32 * (t >> 1) + 4 * (t & 1)) * 128 + chunk);
+                af[t] = *(const bf16x8*)(sa + (wm * 64 + t * 16 + fr) * 128 + chunk);
             }
-            if (EPI == EPI_BF16) {
-                bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-                *(bf16x8*)((bf16*)p.out + orow * p.ldo + n) = o;
-            } else if (EPI == EPI_GELU) {
-                bf16x8 h, g;
+            for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { h[e] = (bf16)v[e]; g[e] = (bf16)gelu_erf((float)h[e]); }
-                *(bf16x8*)((bf16*)p.out + orow * p.ldo + n) = h;
-                *(bf16x8*)((bf16*)p.out2 + orow * p.ldo + n) = g;
-            } else if (EPI == EPI_RESID) {
-                const float* rp = (const float*)p.aux + orow * p.ldaux + n;
-                const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
-                float* op = (float*)p.out + orow * p.ldo + n;
-                *(f32x4*)op = (f32x4){r0[0] + v[0], r0[1] + v[1], r0[2] + v[2], r0[3] + v[3]};
-                *(f32x4*)(op + 4) = (f32x4){r1[0] + v[4], r1[1] + v[5], r1[2] + v[6], r1[3] + v[7]};
-            } else if (EPI == EPI_DGELU) {
-                const bf16x8 h = *(const bf16x8*)((const bf16*)p.aux + orow * p.ldaux + n);
-                bf16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16)(v[e] * gelu_erf_grad((float)h[e]));
-                *(bf16x8*)((bf16*)p.out + orow * p.ldo + n) = o;
-            } else if (EPI == EPI_F32) {
-                float* op = (float*)p.out + orow * p.ldo + n;
-                *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
-                *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-            } else if (EPI == EPI_TOKENS) {
-                const f32x4 t0 = *(const f32x4*)(tab + n), t1 = *(const f32x4*)(tab + n + 4);
-                float* op = (float*)p.out + orow * p.ldo + n;
-                *(f32x4*)op = (f32x4){v[0] + t0[0], v[1] + t0[1], v[2] + t0[2], v[3] + t0[3]};
-                *(f32x4*)(op + 4) = (f32x4){v[4] + t1[0], v[5] + t1[1], v[6] + t1[2], v[7] + t1[3]};
-            } else if (EPI == EPI_UNPATCH) {
-                const int pp = p.P * p.P;
-                const int c = n / pp, rem = n - c * pp, ph = rem / p.P, pw = rem - ph * p.P;
-                const long H = (long)p.NH * p.P, Wd = (long)p.NW * p.P;
-                bf16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-                *(bf16x8*)((bf16*)p.out + (((long)ib * p.C + c) * H + inh * p.P + ph) * Wd + inw * p.P + pw) = o;
-            }
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
         }
+        if (++kt == nk) {
+            int m0, n0;
+            tile_origin(tile, m0, n0);
+            store_wave_tile<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            kt = 0;
+            tile += G;
+        }
+        // everything older than this iteration's 6 loads must have landed (in particular the loads of iteration it+1);
+        // the LDS reads above were consumed by the MFMAs, so after the barrier stage it % 3 may be refilled
+        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 }
 
+// Same ring with 32-deep stages (24 KiB each, 72 KiB per workgroup): two workgroups per CU, so the two waves of a SIMD
+// belong to different workgroups and run out of phase (one computes while the other waits at its barrier).
+// 64-byte LDS rows: chunk c of row r sits at c ^ T[(r >> 2) & 3] (activation tile) or c ^ T[(r >> 3) & 3] (weight tile,
+// whose fragment rows are interleaved), T = {0,2,3,1}: every ds_read_b128 lane group then covers 16 distinct 16-byte slots.
+#define P32_STAGE_BYTES 24576  // A 256x32 bf16 (16 KiB) + W 128x32 bf16 (8 KiB)
+__device__ __forceinline__ int swz32(int a) { return (0x78 >> (2 * a)) & 3; }  // T = {0,2,3,1}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void gemm_nt_persist32_kernel(GemmNT p, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char psmem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int chunk = (fq ^ swz32(fr >> 2)) << 4;  // both tiles: the lane's swizzle key is fr >> 2
+    const int wrow = wn * 64 + 8 * (fr >> 2) + (fr & 3);
+    const int ntiles = tiles_m * tiles_n, G = gridDim.x;
+    const int me = xcd_remap(blockIdx.x, G);
+    const int nk = (p.K + 31) / 32;
+    const int my_tiles = me < ntiles ? (ntiles - 1 - me) / G + 1 : 0;
+    const int total = my_tiles * nk;
+
+    auto tile_origin = [&](int t, int& m0, int& n0) {
+        const int per_group = 4 * tiles_n;
+        const int grp = t / per_group, within = t - grp * per_group;
+        int rows = tiles_m - grp * 4; rows = rows < 4 ? rows : 4;
+        m0 = (grp * 4 + within % rows) * PBM;
+        n0 = (within / rows) * BN;
+    };
+
+    const bf16* a_src[2]; const bf16* w_src;
+    int ka_src[2], kw_src;
+    int ld_tile = me, ld_kt = 0, ld_it = 0;
+    auto set_sources = [&](int t) {
+        int m0, n0;
+        tile_origin(t, m0, n0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {  // 16 rows of 64 B per wave-instruction
+            const int r = (j * 8 + wave) * 16 + (lane >> 2);
+            const int ca = (lane & 3) ^ swz32((r >> 2) & 3);
+            int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
+            a_src[j] = p.A + (long)gm * p.lda + ca * 8;
+            ka_src[j] = ca * 8;
+        }
+        const int r = wave * 16 + (lane >> 2);
+        const int cw = (lane & 3) ^ swz32((r >> 3) & 3);
+        int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
+        w_src = p.W + (long)gn * p.ldw + cw * 8;
+        kw_src = cw * 8;
+    };
+    auto issue = [&]() {
+        char* sa = psmem + (ld_it % PSTAGES) * P32_STAGE_BYTES;
+        char* sw = sa + 16384;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const void* as = ld_kt * 32 + ka_src[j] < p.K ? (const void*)(a_src[j] + ld_kt * 32) : (const void*)g_zero_page;
+            glds16(as, sa + (j * 8 + wave) * 1024);
+        }
+        const void* ws = ld_kt * 32 + kw_src < p.K ? (const void*)(w_src + ld_kt * 32) : (const void*)g_zero_page;
+        glds16(ws, sw + wave * 1024);
+        ++ld_it;
+        if (++ld_kt == nk) {
+            ld_kt = 0;
+            ld_tile += G;
+            if (ld_tile < ntiles) set_sources(ld_tile);
+        }
+    };
+
+    if (total == 0) return;
+    set_sources(ld_tile);
+    issue();
+    if (total > 1) {
+        issue();
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int tile = me, kt = 0;
+    for (int it = 0; it < total; ++it) {
+        const bool more = ld_it < total;
+        if (more) issue();
+        const char* sa = psmem + (it % PSTAGES) * P32_STAGE_BYTES;
+        const char* sw = sa + 16384;
+        bf16x8 wf[4], af[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            wf[t] = *(const bf16x8*)(sw + (wrow + 32 * (t >> 1) + 4 * (t & 1)) * 64 + chunk);
+            af[t] = *(const bf16x8*)(sa + (wm * 64 + t * 16 + fr) * 64 + chunk);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        if (++kt == nk) {
+            int m0, n0;
+            tile_origin(tile, m0, n0);
+            store_wave_tile<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            kt = 0;
+            tile += G;
+        }
+        if (more) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+static int g_num_cus = 0;
+static int num_cus() {
+    if (g_num_cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            g_num_cus = n;
+        else
+            g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+template <int EPI>
+static int launch_nt_persist(const GemmNT& p, hipStream_t s) {
+    static bool reserved = false;
+    constexpr int lds = PSTAGES * PSTAGE_BYTES;
+    if (!reserved) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            mmae_set_error("gemm_nt: cannot reserve %d bytes of LDS: %s", lds, hipGetErrorString(e));
+            return MMAE_ELAUNCH;
+        }
+        reserved = true;
+    }
+    const int tm = (p.M + PBM - 1) / PBM, tn = (p.N + BN - 1) / BN;
+    int grid = tm * tn;
+    const int cus = num_cus();
+    if (grid > cus) grid = cus;
+    hipLaunchKernelGGL(gemm_nt_persist_kernel<EPI>, dim3(grid), dim3(512), lds, s, p, tm, tn);
+    MMAE_CHECK_LAUNCH("gemm_nt_persist");
+    return MMAE_OK;
+}
+
+template <int EPI>
+static int launch_nt_persist32(const GemmNT& p, hipStream_t s) {
+    static bool reserved = false;
+    constexpr int lds = PSTAGES * P32_STAGE_BYTES;
+    if (!reserved) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_persist32_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            mmae_set_error("gemm_nt: cannot reserve %d bytes of LDS: %s", lds, hipGetErrorString(e));
+            return MMAE_ELAUNCH;
+        }
+        reserved = true;
+    }
+    const int tm = (p.M + PBM - 1) / PBM, tn = (p.N + BN - 1) / BN;
+    int grid = tm * tn;
+    const int slots = 2 * num_cus();
+    if (grid > slots) grid = slots;
+    hipLaunchKernelGGL(gemm_nt_persist32_kernel<EPI>, dim3(grid), dim3(512), lds, s, p, tm, tn);
+    MMAE_CHECK_LAUNCH("gemm_nt_persist32");
+    return MMAE_OK;
+}
+
+static int g_nt_variant = 0;  // 0 = choose by size, 1 = always 128x128, 2 = always persistent 256x128
+extern "C" void mmae_gemm_nt_set_variant(int v) { g_nt_variant = v; }
+
 template <int EPI>
 static int launch_nt(const GemmNT& p, hipStream_t s) {
+    const bool big = g_nt_variant == 2;  // measured slower than the 128x128 kernel at every shape of the step so far
+    if (g_nt_variant == 3) return launch_nt_persist32<EPI>(p, s);
+    if (big) return launch_nt_persist<EPI>(p, s);
     const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(tm * tn), dim3(256), 0, s, p);
     MMAE_CHECK_LAUNCH("gemm_nt");

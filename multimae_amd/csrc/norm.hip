@@ -123,20 +123,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
     }
 }
 
-// column sums of the per-block partial rows: 64 columns x 4 row groups per block, fixed order
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, int nblocks, int dim,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              int accumulate) {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+// column sums of the per-block partial rows: 32 columns x 32 row groups per block, fixed order
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ part, int nblocks, int dim,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               int accumulate) {
+    __shared__ float red[32][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float t = 0.f;
     if (c < 2 * dim)
-        for (int b = rg; b < nblocks; b += 4) t += part[(long)b * 2 * dim + c];
+        for (int b = rg; b < nblocks; b += 32) t += part[(long)b * 2 * dim + c];
     red[rg][cl] = t;
     __syncthreads();
     if (rg == 0 && c < 2 * dim) {
-        t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) t += red[r][cl];
         float* dst = c < dim ? dgamma + c : dbeta + (c - dim);
         *dst = accumulate ? *dst + t : t;
     }
@@ -173,7 +175,7 @@ extern "C" int mmae_layernorm_bwd(const void* dy, const float* x, const float* g
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const bf16*)dy, x, gamma, mean, rstd, dres, dx,
                        (bf16*)dx_bf16, (float*)workspace, rows, dim);
     MMAE_CHECK_LAUNCH("layernorm_bwd");
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * dim + 63) / 64), dim3(256), 0, stream, (const float*)workspace, nb, dim,
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * dim + 31) / 32), dim3(1024), 0, stream, (const float*)workspace, nb, dim,
                        dgamma, dbeta, accumulate);
     MMAE_CHECK_LAUNCH("ln_param_reduce");
     return MMAE_OK;

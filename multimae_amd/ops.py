@@ -211,11 +211,12 @@ def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, q_len, kv_len, head_dim, sc
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (d_o, "dO"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
         _req(t, BF16, f"attn_bwd {n}", contiguous=False)
     _req(lse, F32, "attn_bwd lse")
+    ws = workspace(_L().mmae_attn_bwd_workspace_bytes(B, H, q_len), q.device)
     with _Timed("attn_bwd", 8.0 * B * H * q_len * kv_len * head_dim):
         _lib.check(_L().mmae_attn_bwd(_ptr(q), _head_view(q, "q"), _ptr(k), _head_view(k, "k"), _ptr(v), _head_view(v, "v"),
                                       _ptr(o), _head_view(o, "o"), _ptr(d_o), _head_view(d_o, "dO"), _ptr(lse),
                                       _ptr(dq), _head_view(dq, "dq"), _ptr(dk), _head_view(dk, "dk"), _ptr(dv), _head_view(dv, "dv"),
-                                      B, H, q_len, kv_len, head_dim, float(scale), _stream()), "attn_bwd")
+                                      B, H, q_len, kv_len, head_dim, float(scale), _ptr(ws), ws.numel(), _stream()), "attn_bwd")
 
 
 # --------------------------------------------------------------------------------------------- masking

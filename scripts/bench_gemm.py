@@ -29,8 +29,15 @@ for name, m, n, k, epi in shapes_nt:
     a, w = r(m, k), r(n, k)
     bias = torch.randn(n, device="cuda")
     aux = r(m, n, dt=torch.float32) if epi == 2 else (r(m, n) if epi == 3 else None)
-    t = timeit(lambda: ops.gemm_nt(epi, a, w, None if epi == 3 else bias, aux=aux))
-    print(f"gemm_nt {name:10s} M={m} N={n} K={k}: {t*1e6:8.1f} us  {2*m*n*k/t/1e12:7.1f} TF")
+    res = []
+    for variant in (1, 2, 3):
+        ops._L().mmae_gemm_nt_set_variant(variant)
+        t = timeit(lambda: ops.gemm_nt(epi, a, w, None if epi == 3 else bias, aux=aux))
+        res.append(f"{t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
+    ops._L().mmae_gemm_nt_set_variant(0)
+    print(f"gemm_nt {name:10s} M={m} N={n} K={k}: t128 {res[0]} | p256 {res[1]} | p256k32 {res[2]}")
+if len(sys.argv) > 1 and sys.argv[1] == "nt":
+    sys.exit(0)
 for name, m, n, k in [("dW qkv", M, 2304, 768), ("dW proj", M, 768, 768), ("dW fc1", M, 3072, 768), ("dW fc2", M, 768, 3072),
                       ("dW dec fc1", 50176, 1024, 256), ("dW dec proj", 50176, 256, 256)]:
     x, y = r(m, n), r(m, k)
