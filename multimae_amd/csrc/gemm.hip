@@ -216,9 +216,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
 #define PSTAGE_BYTES 49152  // A 256x64 bf16 (32 KiB) + W 128x64 bf16 (16 KiB)
 #define PSTAGES 3
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmNT p, int tiles_m, int tiles_n) {
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else static_assert(N == 0, "add the immediate");
+}
+
+// WM = waves along M (2 -> 128-row tile, 256 threads; 4 -> 256-row tile, 512 threads); two waves along N (128 columns).
+template <int EPI, int WM, int STAGES>
+__global__ __launch_bounds__(WM * 128, (WM == 4 ? 2 : 2)) void gemm_nt_persist_kernel(GemmNT p, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char psmem[];
+    constexpr int NWV = WM * 2, TBM = WM * 64, A_BYTES = TBM * 128, STAGE = A_BYTES + 16384;
+    constexpr int WI = 8 / WM;                 // weight-tile LDS-DMA instructions per thread and stage
+    constexpr int LOADS = 4 + WI;              // per thread and stage
+    constexpr int RASTER = 1024 / TBM;         // row-tiles per raster group (1024 rows)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fq = lane >> 4, swz = fr >> 1;
@@ -229,50 +241,50 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmNT p, int t
     const int my_tiles = me < ntiles ? (ntiles - 1 - me) / G + 1 : 0;
     const int total = my_tiles * nk;
 
-    auto tile_origin = [&](int t, int& m0, int& n0) {  // groups of 4 row-tiles x all column-tiles, rows fastest
-        const int per_group = 4 * tiles_n;
+    auto tile_origin = [&](int t, int& m0, int& n0) {  // groups of RASTER row-tiles x all column-tiles, rows fastest
+        const int per_group = RASTER * tiles_n;
         const int grp = t / per_group, within = t - grp * per_group;
-        int rows = tiles_m - grp * 4; rows = rows < 4 ? rows : 4;
-        m0 = (grp * 4 + within % rows) * PBM;
+        int rows = tiles_m - grp * RASTER; rows = rows < RASTER ? rows : RASTER;
+        m0 = (grp * RASTER + within % rows) * TBM;
         n0 = (within / rows) * BN;
     };
 
     // ---- load cursor ----
-    const bf16* a_src[4]; const bf16* w_src[2];
-    int ka_src[4], kw_src[2];
+    const bf16* a_src[4]; const bf16* w_src[WI];
+    int ka_src[4], kw_src[WI];
     int ld_tile = me, ld_kt = 0, ld_it = 0;
     auto set_sources = [&](int t) {
         int m0, n0;
         tile_origin(t, m0, n0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int r = (j * 8 + wave) * 8 + (lane >> 3);
+            const int r = (j * NWV + wave) * 8 + (lane >> 3);
             const int ca = (lane & 7) ^ ((r >> 1) & 7);
             int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
             a_src[j] = p.A + (long)gm * p.lda + ca * 8;
             ka_src[j] = ca * 8;
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = (j * 8 + wave) * 8 + (lane >> 3);
+        for (int j = 0; j < WI; ++j) {
+            const int r = (j * NWV + wave) * 8 + (lane >> 3);
             const int cw = (lane & 7) ^ (((r >> 1) & 1) | (((r >> 3) & 3) << 1));
             int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
             w_src[j] = p.W + (long)gn * p.ldw + cw * 8;
             kw_src[j] = cw * 8;
         }
     };
-    auto issue = [&]() {  // loads of ring iteration ld_it (6 LDS-DMA per thread)
-        char* sa = psmem + (ld_it % PSTAGES) * PSTAGE_BYTES;
-        char* sw = sa + 32768;
+    auto issue = [&]() {  // loads of ring iteration ld_it
+        char* sa = psmem + (ld_it % STAGES) * STAGE;
+        char* sw = sa + A_BYTES;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const void* as = ld_kt * BKT + ka_src[j] < p.K ? (const void*)(a_src[j] + ld_kt * BKT) : (const void*)g_zero_page;
-            glds16(as, sa + (j * 8 + wave) * 1024);
+            glds16(as, sa + (j * NWV + wave) * 1024);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < WI; ++j) {
             const void* ws = ld_kt * BKT + kw_src[j] < p.K ? (const void*)(w_src[j] + ld_kt * BKT) : (const void*)g_zero_page;
-            glds16(ws, sw + (j * 8 + wave) * 1024);
+            glds16(ws, sw + (j * NWV + wave) * 1024);
         }
         ++ld_it;
         if (++ld_kt == nk) {
@@ -284,12 +296,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmNT p, int t
 
     if (total == 0) return;
     set_sources(ld_tile);
+    // prologue: fill STAGES-1 stages, wait for the first
     issue();
-    if (total > 1) {
+    if (STAGES == 3 && total > 1) {
         issue();
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        wait_vmcnt<LOADS>();
     } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
 
@@ -302,9 +315,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmNT p, int t
     int tile = me, kt = 0;
     for (int it = 0; it < total; ++it) {
         const bool more = ld_it < total;
-        if (more) issue();  // ring iteration it+2 -> stage (it+2) % 3, last read in iteration it-1
-        const char* sa = psmem + (it % PSTAGES) * PSTAGE_BYTES;
-        const char* sw = sa + 32768;
+        if (more) issue();  // ring iteration it+STAGES-1 -> the stage last read in iteration it-1
+        const char* sa = psmem + (it % STAGES) * STAGE;
+        const char* sw = sa + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int chunk = ((ks * 4 + fq) ^ swz) << 4;
@@ -331,10 +344,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmNT p, int t
             kt = 0;
             tile += G;
         }
-        // everything older than this iteration's 6 loads must have landed (in particular the loads of iteration it+1);
-        // the LDS reads above were consumed by the MFMAs, so after the barrier stage it % 3 may be refilled
-        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // everything older than the newest STAGES-2 stages of loads must have landed (in particular iteration it+1);
+        // the LDS reads above were consumed by the MFMAs, so after the barrier stage it % STAGES may be refilled
+        if (STAGES == 3 && more) wait_vmcnt<LOADS>();
+        else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -471,23 +484,23 @@ static int num_cus() {
     return g_num_cus;
 }
 
-template <int EPI>
+template <int EPI, int WM, int STAGES>
 static int launch_nt_persist(const GemmNT& p, hipStream_t s) {
     static bool reserved = false;
-    constexpr int lds = PSTAGES * PSTAGE_BYTES;
+    constexpr int lds = STAGES * (WM * 64 * 128 + 16384);
     if (!reserved) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<EPI, WM, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             mmae_set_error("gemm_nt: cannot reserve %d bytes of LDS: %s", lds, hipGetErrorString(e));
             return MMAE_ELAUNCH;
         }
         reserved = true;
     }
-    const int tm = (p.M + PBM - 1) / PBM, tn = (p.N + BN - 1) / BN;
+    const int tm = (p.M + WM * 64 - 1) / (WM * 64), tn = (p.N + BN - 1) / BN;
     int grid = tm * tn;
-    const int cus = num_cus();
-    if (grid > cus) grid = cus;
-    hipLaunchKernelGGL(gemm_nt_persist_kernel<EPI>, dim3(grid), dim3(512), lds, s, p, tm, tn);
+    const int slots = num_cus() * (lds <= 80 * 1024 ? 2 : 1);
+    if (grid > slots) grid = slots;
+    hipLaunchKernelGGL((gemm_nt_persist_kernel<EPI, WM, STAGES>), dim3(grid), dim3(WM * 128), lds, s, p, tm, tn);
     MMAE_CHECK_LAUNCH("gemm_nt_persist");
     return MMAE_OK;
 }
@@ -518,9 +531,13 @@ extern "C" void mmae_gemm_nt_set_variant(int v) { g_nt_variant = v; }
 
 template <int EPI>
 static int launch_nt(const GemmNT& p, hipStream_t s) {
-    const bool big = g_nt_variant == 2;  // measured slower than the 128x128 kernel at every shape of the step so far
+    // Measured on MI355X at the shapes of the ViT-B step: the persistent 128x128 ring wins where a workgroup gets many
+    // tiles of a short K loop (N >= 2048: +6..11 %), the plain 128x128 grid elsewhere; the 256-row rings are slower.
+    const long tiles128 = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    if (g_nt_variant == 2) return launch_nt_persist<EPI, 4, 3>(p, s);
     if (g_nt_variant == 3) return launch_nt_persist32<EPI>(p, s);
-    if (big) return launch_nt_persist<EPI>(p, s);
+    if (g_nt_variant == 4 || (g_nt_variant == 0 && p.N >= 2048 && tiles128 >= 4 * 2 * num_cus()))
+        return launch_nt_persist<EPI, 2, 2>(p, s);
     const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(tm * tn), dim3(256), 0, s, p);
     MMAE_CHECK_LAUNCH("gemm_nt");

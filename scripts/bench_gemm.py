@@ -30,12 +30,12 @@ for name, m, n, k, epi in shapes_nt:
     bias = torch.randn(n, device="cuda")
     aux = r(m, n, dt=torch.float32) if epi == 2 else (r(m, n) if epi == 3 else None)
     res = []
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4):
         ops._L().mmae_gemm_nt_set_variant(variant)
         t = timeit(lambda: ops.gemm_nt(epi, a, w, None if epi == 3 else bias, aux=aux))
         res.append(f"{t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
     ops._L().mmae_gemm_nt_set_variant(0)
-    print(f"gemm_nt {name:10s} M={m} N={n} K={k}: t128 {res[0]} | p256 {res[1]} | p256k32 {res[2]}")
+    print(f"gemm_nt {name:10s} M={m} N={n} K={k}: t128 {res[0]} | p256 {res[1]} | p256k32 {res[2]} | p128 {res[3]}")
 if len(sys.argv) > 1 and sys.argv[1] == "nt":
     sys.exit(0)
 for name, m, n, k in [("dW qkv", M, 2304, 768), ("dW proj", M, 768, 768), ("dW fc1", M, 3072, 768), ("dW fc2", M, 768, 3072),

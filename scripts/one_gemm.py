@@ -1,14 +1,19 @@
-"""Runs one kernel shape a few times (for rocprofv3 --pmc passes): python3 scripts/one_gemm.py {nt|tn|attn_bwd|attn_fwd}"""
+"""Runs one kernel shape a few times (for rocprofv3 --pmc passes): python3 scripts/one_gemm.py {nt|ntk|tn|attn_bwd|attn_fwd} [variant]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from multimae_amd import ops
 which = sys.argv[1] if len(sys.argv) > 1 else "nt"
+if len(sys.argv) > 2:
+    ops._L().mmae_gemm_nt_set_variant(int(sys.argv[2]))
 M = 25344
 r = lambda *s: (torch.randn(*s, device="cuda") * 0.5).to(torch.bfloat16)
-if which == "nt":
-    a, w, b = r(M, 768), r(3072, 768), torch.randn(3072, device="cuda")
-    fn = lambda: ops.gemm_nt(1, a, w, b)
+if which == "nt":      # qkv: plain bf16 epilogue, K=768
+    a, w, b = r(M, 768), r(2304, 768), torch.randn(2304, device="cuda")
+    fn = lambda: ops.gemm_nt(0, a, w, b)
+elif which == "ntk":   # long K
+    a, w = r(M, 3072), r(768, 3072)
+    fn = lambda: ops.gemm_nt(0, a, w, None)
 elif which == "tn":
     x, y = r(M, 3072), r(M, 768)
     out = torch.zeros(3072, 768, device="cuda")

@@ -63,6 +63,20 @@ def test_seeded_init_is_bitwise_the_references():
     assert all(torch.equal(ref[k], mine[k]) for k in ref)
 
 
+def test_compat_aliases():
+    import multimae_amd
+    from multimae_amd import compat
+    prev = compat.install()
+    try:
+        from multimae import MultiMAE, PatchedInputAdapter, SpatialOutputAdapter  # noqa: F401
+        from multimae.criterion import MaskedL1Loss, MaskedMSELoss  # noqa: F401
+        from multimae.multimae import pretrain_multimae_base  # noqa: F401
+        assert MultiMAE is multimae_amd.MultiMAE and MaskedMSELoss is multimae_amd.MaskedMSELoss
+    finally:
+        compat.uninstall(prev)
+    assert sys.modules.get("multimae") is not multimae_amd
+
+
 def test_no_cpu_fallback():
     from multimae_amd import _lib
     from oracle import multimae_oracle as O
