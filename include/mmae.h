@@ -175,6 +175,10 @@ int mmae_adamw_flat(float* p, const float* g, float* m, float* v, long n, long n
 int mmae_sumsq(const float* x, long n, float* out, void* workspace, size_t workspace_bytes, mmae_stream_t stream);
 /* dst(bf16)[rows, cols] = src(f32)[rows, cols]; dst_t(bf16)[cols, rows] = transpose (either may be NULL) */
 int mmae_cast_transpose(const float* src, int rows, int cols, void* dst_bf16, void* dst_t_bf16, mmae_stream_t stream);
+/* Transposed copies of many 2-D bf16 tensors in one launch: table[t] = {element offset, rows, cols, first 64x64 tile};
+ * tensor t is [rows, cols] at src + offset and is written as [cols, rows] at dst + offset (device int32 table). */
+int mmae_transpose_multi(const void* src_bf16, void* dst_bf16, const int* table, int n_tensors, int total_tiles,
+                         mmae_stream_t stream);
 /* y(bf16) = x(f32) elementwise */
 int mmae_cast_bf16(const float* x, void* y_bf16, long n, mmae_stream_t stream);
 

@@ -43,6 +43,7 @@ SIGNATURES = {
     "mmae_adamw_flat": (_i, [_p, _p, _p, _p, _l, _l, _f, _f, _f, _f, _f, _i, _f, _p, _p]),
     "mmae_sumsq": (_i, [_p, _l, _p, _p, _z, _p]),
     "mmae_cast_transpose": (_i, [_p, _i, _i, _p, _p, _p]),
+    "mmae_transpose_multi": (_i, [_p, _p, _p, _i, _i, _p]),
     "mmae_cast_bf16": (_i, [_p, _p, _l, _p]),
 }
 

@@ -124,3 +124,47 @@ extern "C" int mmae_cast_bf16(const float* x, void* y_bf16, long n, hipStream_t 
     MMAE_CHECK_LAUNCH("cast_bf16");
     return MMAE_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Transposed bf16 copies of many 2-D weights in one launch.  src and dst are flat bf16 buffers with the same element
+// offsets; table[t] = {offset, rows, cols, first tile} describes tensor t ([rows, cols] at src + offset, transposed to
+// [cols, rows] at dst + offset); tiles are 64x64 and numbered tensor by tensor.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst,
+                                                              const int4* __restrict__ table, int n_tensors) {
+    __shared__ bf16 tile[64][66];
+    // binary search for the tensor that owns this tile
+    int lo = 0, hi = n_tensors - 1;
+    const int tid_blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].w <= tid_blk) lo = mid; else hi = mid - 1;
+    }
+    const int4 d = table[lo];
+    const int rows = d.y, cols = d.z;
+    const int tiles_c = (cols + 63) / 64;
+    const int t = tid_blk - d.w;
+    const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    const bf16* s = src + d.x;
+    bf16* o = dst + d.x;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? s[(long)r * cols + c] : (bf16)0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < rows && c < cols) o[(long)c * rows + r] = tile[tx][i];
+    }
+}
+
+extern "C" int mmae_transpose_multi(const void* src_bf16, void* dst_bf16, const int* table, int n_tensors, int total_tiles,
+                                    hipStream_t stream) {
+    MMAE_REQUIRE(src_bf16 && dst_bf16 && table, MMAE_EINVAL, "transpose_multi: null pointer");
+    if (n_tensors <= 0 || total_tiles <= 0) return MMAE_OK;
+    hipLaunchKernelGGL(transpose_multi_kernel, dim3(total_tiles), dim3(256), 0, stream, (const bf16*)src_bf16, (bf16*)dst_bf16,
+                       (const int4*)table, n_tensors);
+    MMAE_CHECK_LAUNCH("transpose_multi");
+    return MMAE_OK;
+}

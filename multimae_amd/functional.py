@@ -5,6 +5,8 @@ stream, LayerNorm statistics, softmax and the losses are fp32; every matrix prod
 accumulates in fp32.  Each function saves exactly what its backward kernels read."""
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import weakref
+
 import torch
 
 from . import ops
@@ -23,7 +25,14 @@ def bump_weight_epoch():
 
 
 def bf16_weights(w: torch.Tensor):
-    """(w as bf16 [N,K], w^T as bf16 [K,N]) for a 2-D fp32 parameter, cached until the parameter changes."""
+    """(w as bf16 [N,K], w^T as bf16 [K,N]) for a 2-D fp32 parameter, cached until the parameter changes.
+    Parameters in flat storage carry views of the flat bf16 copies that the optimizer step refreshes in two launches."""
+    views = getattr(w, "_mmae_bf16_views", None)
+    if views is not None:
+        if w._version != views[2]:  # written through autograd-visible ops (load_state_dict, copy_) since the last sync
+            views[3]()
+            views = w._mmae_bf16_views
+        return views[0], views[1]
     key = id(w)
     ent = _WEIGHT_CACHE.get(key)
     ver = (w._version, _WEIGHT_EPOCH, w.data_ptr())
@@ -38,8 +47,31 @@ def clear_weight_cache():
     _WEIGHT_CACHE.clear()
 
 
+# bf16 shadow of the fp32 gradient that a LayerNorm backward just produced: the next consumer needs both precisions
+# (fp32 for the residual path, bf16 as a GEMM operand).  One entry at most; valid only while the producer tensor is alive
+# and the consumer's tensor is the same, unmodified memory.
+_SHADOW = None
+
+
+def _set_shadow(dx: torch.Tensor, dxb: torch.Tensor):
+    global _SHADOW
+    _SHADOW = (weakref.ref(dx), dx.data_ptr(), dx.numel(), dxb, dx._version)
+
+
+def clear_shadow():
+    global _SHADOW
+    _SHADOW = None
+
+
 def _bf16(g: torch.Tensor) -> torch.Tensor:
-    return g if g.dtype == torch.bfloat16 else ops.cast_bf16(g.contiguous())
+    global _SHADOW
+    if g.dtype == torch.bfloat16:
+        return g
+    ent, _SHADOW = _SHADOW, None
+    if (ent is not None and ent[0]() is not None and ent[1] == g.data_ptr() and ent[2] == g.numel() and g.is_contiguous()
+            and g._version == ent[4]):  # same memory, producer still alive, not accumulated into in place since
+        return ent[3].reshape(g.shape)
+    return ops.cast_bf16(g.contiguous())
 
 
 def _direct(p) -> bool:
@@ -69,14 +101,17 @@ def _lin_grads(dy_b: torch.Tensor, x_b: torch.Tensor, w=None, b=None):
     return ops.gemm_tn(dy_b, x_b), None
 
 
-def _ln_bwd(dy, x, n_w, n_b, mean, rstd, dres=None):
+def _ln_bwd(dy, x, n_w, n_b, mean, rstd, dres=None, shadow=False):
     """LayerNorm backward; (dx, dgamma, dbeta) with the parameter gradients None when written in place."""
     if _direct(n_w) and _direct(n_b):
-        dx = ops.layernorm_bwd(dy, x, n_w, mean, rstd, dres=dres, dgamma=n_w.grad, dbeta=n_b.grad)[0]
+        dx, dxb, _, _ = ops.layernorm_bwd(dy, x, n_w, mean, rstd, dres=dres, want_bf16=shadow, dgamma=n_w.grad, dbeta=n_b.grad)
         _ready(n_w)
         _ready(n_b)
-        return dx, None, None
-    dx, _, dg, db = ops.layernorm_bwd(dy, x, n_w, mean, rstd, dres=dres)
+        dg = db = None
+    else:
+        dx, dxb, dg, db = ops.layernorm_bwd(dy, x, n_w, mean, rstd, dres=dres, want_bf16=shadow)
+    if shadow:
+        _set_shadow(dx, dxb)
     return dx, dg, db
 
 
@@ -101,7 +136,7 @@ def _mlp_bwd(g, saved):
     dw2, db2 = _lin_grads(gb, act, fc2_w, fc2_b)
     dln = ops.gemm_nt(ops.EPI_BF16, dh, w1t, None)
     dw1, db1 = _lin_grads(dh, ln, fc1_w, fc1_b)
-    dx, dnw, dnb = _ln_bwd(dln, x, n_w, n_b, mean, rstd, dres=g)
+    dx, dnw, dnb = _ln_bwd(dln, x, n_w, n_b, mean, rstd, dres=g, shadow=True)  # consumed right after (attention half / decoder head)
     return dx, [dnw, dnb, dw1, db1, dw2, db2]
 
 
@@ -129,7 +164,7 @@ def _self_attn_bwd(g, saved):
                  B, heads, N, N, d, d ** -0.5)
     dln = ops.gemm_nt(ops.EPI_BF16, dqkv, wqt, None)
     dwq, dbq = _lin_grads(dqkv, ln, qkv_w, qkv_b)
-    dx, dnw, dnb = _ln_bwd(dln, x, n_w, n_b, mean, rstd, dres=g)
+    dx, dnw, dnb = _ln_bwd(dln, x, n_w, n_b, mean, rstd, dres=g, shadow=True)  # consumed by the previous block
     return dx, [dnw, dnb, dwq, dbq, dwp, dbp]
 
 

@@ -394,3 +394,10 @@ def cast_bf16(x: torch.Tensor):
     y = torch.empty(x.shape, dtype=BF16, device=x.device)
     _lib.check(_L().mmae_cast_bf16(_ptr(x), _ptr(y), x.numel(), _stream()), "cast_bf16")
     return y
+
+
+def transpose_multi(src_flat: torch.Tensor, dst_flat: torch.Tensor, table: torch.Tensor, total_tiles: int):
+    """table: int32 [n,4] on the device = (offset, rows, cols, first tile) per 2-D tensor inside the flat bf16 buffers."""
+    _req(src_flat, BF16, "transpose_multi src"); _req(dst_flat, BF16, "transpose_multi dst"); _req(table, torch.int32, "transpose_multi table")
+    _lib.check(_L().mmae_transpose_multi(_ptr(src_flat), _ptr(dst_flat), _ptr(table), table.shape[0], int(total_tiles), _stream()),
+               "transpose_multi")

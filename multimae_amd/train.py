@@ -61,8 +61,8 @@ class FlatParams:
         self.named = decay + no_decay
         dev = self.named[0][1].device
 
-        def padded(n):  # keep every view 16-byte aligned
-            return (n + 3) // 4 * 4
+        def padded(n):  # keep every view 16-byte aligned, in the fp32 buffers and in their bf16 copies
+            return (n + 7) // 8 * 8
         self.offsets, off = [], 0
         for _, p in decay:
             self.offsets.append(off)
@@ -82,6 +82,38 @@ class FlatParams:
                 p.grad = self.grads[o:o + p.numel()].view(p.shape)
                 p._mmae_direct = True  # kernels may accumulate this parameter's gradient in place
         Fn.clear_weight_cache()
+        # bf16 copies for the GEMMs: W ([out,in], same layout as the fp32 master, written by the AdamW kernel) and W^T
+        # (one multi-tensor transpose launch); every 2-D Linear weight views into these two flat buffers
+        self.w_bf16 = self.wt_bf16 = self._tr_table = None
+        if dev.type == "cuda":
+            self.w_bf16 = torch.empty(off, dtype=torch.bfloat16, device=dev)
+            self.wt_bf16 = torch.empty_like(self.w_bf16)
+            rows, tiles = [], 0
+            for (name, p), o in zip(self.named, self.offsets):
+                if p.ndim == 2:
+                    n, k = p.shape
+                    rows.append([o, n, k, tiles])
+                    tiles += ((n + 63) // 64) * ((k + 63) // 64)
+            self._tr_table = torch.tensor(rows, dtype=torch.int32, device=dev) if rows else None
+            self._tr_tiles = tiles
+            self.sync_bf16()
+
+    def refresh_transposes(self):
+        if self._tr_table is not None:
+            ops.transpose_multi(self.w_bf16, self.wt_bf16, self._tr_table, self._tr_tiles)
+
+    def sync_bf16(self):
+        """Rebuild both bf16 copies from the fp32 master and re-arm the per-parameter views (needed after the
+        parameters were written by anything other than FlatAdamW.step, which keeps the copies current itself)."""
+        if self.w_bf16 is None:
+            return
+        self.w_bf16.copy_(ops.cast_bf16(self.params))
+        self.refresh_transposes()
+        for (name, p), o in zip(self.named, self.offsets):
+            if p.ndim == 2:
+                n, k = p.shape
+                p._mmae_bf16_views = (self.w_bf16[o:o + n * k].view(n, k), self.wt_bf16[o:o + n * k].view(k, n),
+                                      p._version, self.sync_bf16)
 
     def zero_grad(self):
         self.grads.zero_()
@@ -101,7 +133,7 @@ class GradBuckets:
         self.bucket_of = {}
         cur = None
         for i, ((_, p), o) in enumerate(zip(flat.named, flat.offsets)):
-            end = o + (p.numel() + 3) // 4 * 4
+            end = o + (p.numel() + 7) // 8 * 8
             boundary = (o == flat.n_decay)  # never mix the two regions
             if cur is None or boundary or end - cur[0] > cap:
                 cur = [o, end, 0]
@@ -155,7 +187,9 @@ class FlatAdamW:
     def step(self, grad_scale: float = 1.0):
         self.step_count += 1
         ops.adamw_flat(self.flat.params, self.flat.grads, self.exp_avg, self.exp_avg_sq, self.flat.n_decay, self.lr,
-                       self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale)
+                       self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale,
+                       w_bf16=self.flat.w_bf16)
+        self.flat.refresh_transposes()
         Fn.bump_weight_epoch()
 
     def grad_norm_sq(self):

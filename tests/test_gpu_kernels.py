@@ -316,3 +316,19 @@ def test_masked_loss_full_size_vs_oracle(ops, C):
         ref2.backward()
         assert abs(lb.item() - ref2.item()) / abs(ref2.item()) < FP32_TOL and db.dtype == torch.bfloat16
         assert rel_err(db.float().cpu(), pr2.grad) < 4e-3
+
+
+def test_transpose_multi_matches_torch(ops):
+    torch.manual_seed(3)
+    shapes = [(768, 2304), (100, 36), (64, 64), (8, 264), (3072, 768)]
+    offs, off, rows, tiles = [], 0, [], 0
+    for n, k in shapes:
+        offs.append(off)
+        rows.append([off, n, k, tiles])
+        tiles += ((n + 63) // 64) * ((k + 63) // 64)
+        off += (n * k + 7) // 8 * 8
+    src = torch.randn(off, device="cuda").bfloat16()
+    dst = torch.zeros_like(src)
+    ops.transpose_multi(src, dst, torch.tensor(rows, dtype=torch.int32, device="cuda"), tiles)
+    for (n, k), o in zip(shapes, offs):
+        assert torch.equal(dst[o:o + n * k].view(k, n), src[o:o + n * k].view(n, k).t())

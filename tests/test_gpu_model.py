@@ -171,3 +171,52 @@ def test_flat_storage_step_matches_autograd_path():
     # a second step runs on the updated weights (bf16 weight copies must be refreshed)
     loss2, _, _ = step(x, mask_randomness=rnd)
     assert torch.isfinite(loss2) and loss2.item() != loss.item()
+
+
+def test_vit_l_384_shapes_vs_oracle():
+    """Shapes of the ViT-L/16 384^2 configuration (dim 1024, 16 heads, 576 tokens per domain, 288 visible + 1 global,
+    decoders over 576 queries) on a 2-layer encoder / 1-layer decoders so the host oracle stays fast."""
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    out = {"rgb": (3, "rgb"), "depth": (1, "depth"), "norm_rgb": (3, "rgb")}
+    cfg = O.make_cfg({"rgb": 3, "depth": 1}, out, dim=1024, depth=2, heads=16, dec_dim=256, dec_depth=1, dec_heads=8, image=384)
+    sd = G.perturbed_state(cfg, seed=11)
+    B, k = 2, 288
+    x = G.seeded_inputs(cfg, B=B, seed=12)
+    p, noises, noise_all = O.draw_mask_randomness(B, [576, 576], 1.0, torch.Generator().manual_seed(13))
+    o_losses, o_preds, o_masks, o_grads = O.step_grads(sd, cfg, x, p, noises, noise_all, k)
+    model = _build(cfg)
+    model.load_state_dict(sd, strict=True)
+    model.cuda()
+    preds, masks, losses, grads = _hip_step(model, cfg, x, (p, noises, noise_all), k)
+    for d in masks:
+        assert torch.equal(masks[d].cpu(), o_masks[d]), d
+    errs = {f"pred_{t}": rel_err(preds[t].float().cpu(), o_preds[t]) for t in preds}
+    errs.update({f"loss_{t}": abs(losses[t].item() - float(o_losses[t])) / abs(float(o_losses[t])) for t in losses})
+    gerr = {n: rel_err(g.cpu(), o_grads[n]) for n, g in grads.items()}
+    print({k_: f"{v:.2e}" for k_, v in errs.items()}, "worst grads:", sorted(((e, n) for n, e in gerr.items()), reverse=True)[:4])
+    assert all(v < BF16_TOL for v in errs.values()), errs
+    assert all(e < BF16_TOL for e in gerr.values()), {n: e for n, e in gerr.items() if e >= BF16_TOL}
+
+
+def test_flat_bf16_weight_copies_track_the_master():
+    """Flat storage keeps bf16 W / W^T views current across optimizer steps and re-syncs them after an
+    autograd-visible write (load_state_dict, copy_)."""
+    from multimae_amd import functional as Fn
+    from multimae_amd.train import FlatAdamW, FlatParams
+    from oracle import multimae_oracle as O
+    cfg = O.small_cfg()
+    model = _build(cfg).cuda()
+    flat = FlatParams(model)
+    opt = FlatAdamW(flat, lr=1e-2, weight_decay=0.05)
+    w = model.encoder[0].mlp.fc1.weight
+    wb, wt = Fn.bf16_weights(w)
+    assert torch.equal(wb, w.detach().bfloat16()) and torch.equal(wt, w.detach().bfloat16().t())
+    flat.grads.normal_()
+    opt.step()
+    wb, wt = Fn.bf16_weights(w)
+    assert torch.equal(wb, w.detach().bfloat16()) and torch.equal(wt, w.detach().bfloat16().t())
+    with torch.no_grad():
+        w.mul_(1.5)
+    wb, wt = Fn.bf16_weights(w)
+    assert torch.equal(wb, w.detach().bfloat16()) and torch.equal(wt, w.detach().bfloat16().t())
