@@ -62,9 +62,9 @@ int mmae_patch_embed_gemm(const void* A, const void* W, int M, int N, int K, con
                           int seg_in, int seg_out, float* out, long ldo, mmae_stream_t stream);
 
 /* out_proj + "b (nh nw) (c ph pw) -> b c (nh ph) (nw pw)" store (multimae/output_adapters.py:361-372);
- * out_image is bf16 [M/(NH*NW), C, NH*P, NW*P]. */
+ * out_image is bf16 or f32 (out_is_f32) [M/(NH*NW), C, NH*P, NW*P]; P = patch_size_full / stride_level, a multiple of 4. */
 int mmae_unpatchify_gemm(const void* A, long lda, const void* W, int M, int N, int K, const float* bias,
-                         void* out_image, int C, int P, int NH, int NW, mmae_stream_t stream);
+                         void* out_image, int out_is_f32, int C, int P, int NH, int NW, mmae_stream_t stream);
 
 /* mmae_gemm_tn: out[N,K] (f32) (+)= X[M,N]^T x Y[M,K]: the weight-gradient half of nn.Linear backward
  * (dW = dC^T x A).  Split over M into fp32 slabs held in `workspace`, then reduced in a fixed order
@@ -118,8 +118,14 @@ int mmae_mask_generate(const float* task_dist, const float* noise, const float* 
 /* ---- token plumbing ------------------------------------------------------------------------- */
 /* Pack the kept patches as bf16 rows of the K-concatenated patch matrix:
  * row (b*k + j) = [0 .. | patch (c,ph,pw) of token ids_keep[b,j] in its domain's column block | .. 0].
- * images_host: T device pointers to f32 [B,C_t,H,W] passed by value in a host array. */
-int mmae_pack_patches(const float* const* images_host, const int* channels_host, int T, int B, int H, int W, int P,
+ * Every domain shares the NH x NW token grid; domain t has its own patch edge patch_host[t] (patch_size_full /
+ * stride_level, multimae/input_adapters.py:64-65; a multiple of 4) and image size NH*P_t x NW*P_t.
+ * images_host: T device pointers passed by value in a host array: f32 [B,C_t,H_t,W_t], or, for a class-map domain
+ * (class_emb_host[t] != NULL: f32 [num_classes_host[t], C_t] embedding table; the call site of the reference's
+ * SemSegInputAdapter is run_pretraining_multimae.py:72-85), i64 class ids [B,H_t,W_t] whose pixels are table rows.
+ * Class ids outside [0, num_classes) are clamped.  class_emb_host / num_classes_host may be NULL (no class maps). */
+int mmae_pack_patches(const void* const* images_host, const int* channels_host, const int* patch_host,
+                      const float* const* class_emb_host, const int* num_classes_host, int T, int B, int NH, int NW,
                       const int* ids_keep_i32, int k, void* out_bf16, int Ktot, mmae_stream_t stream);
 /* The column block after the patches holds one-hot(domain) so that the weight-gradient GEMM over the packed
  * rows also yields the per-domain Conv2d bias gradient; Ktot >= sum_t C_t*P*P + 8, a multiple of 64. */
@@ -151,8 +157,18 @@ int mmae_decoder_assemble_bwd(const float* d_queries, const float* d_context, co
 int mmae_build_decoder_emb(const float* const* task_emb_host, const float* pos_emb, int T, int ntok, int Dd, float* emb,
                            mmae_stream_t stream);
 
-/* image (bf16 [B,C,H,W]) -> token rows (bf16 [B*NH*NW, C*P*P]): the adjoint of the un-patchify store */
-int mmae_patchify_bf16(const void* image, int B, int C, int NH, int NW, int P, void* rows, mmae_stream_t stream);
+/* image (bf16 or f32 [B,C,H,W]) -> token rows (bf16 [B*NH*NW, C*P*P]): the adjoint of the un-patchify store */
+int mmae_patchify_bf16(const void* image, int image_is_f32, int B, int C, int NH, int NW, int P, void* rows, mmae_stream_t stream);
+
+/* Class-embedding gradient of a class-map input domain (nn.Embedding backward of the SemSegInputAdapter named at
+ * run_pretraining_multimae.py:72-85): d_emb[cls, c] (+)= sum over the domain's kept tokens (ids_keep in
+ * [tok_start, tok_start + NH*NW)) and their P*P pixels of class cls of dA[row, c*P*P + ph*P + pw], where dA (bf16,
+ * row stride ldd) is the gradient of the packed patch rows restricted to this domain's columns.  Fixed summation
+ * order (bitwise reproducible). */
+size_t mmae_class_emb_bwd_workspace_bytes(int num_classes, int dim_emb);
+int mmae_class_emb_bwd(const void* dA_bf16, long ldd, const int64_t* class_map, const int* ids_keep_i32, int B, int k,
+                       int tok_start, int NH, int NW, int P, int num_classes, int dim_emb, float* d_emb, int accumulate,
+                       void* workspace, size_t workspace_bytes, mmae_stream_t stream);
 
 /* ---- masked losses (multimae/criterion.py:96-130, :161-195) ----------------------------------
  * kind 0 = MSE, 1 = L1; norm_pix standardises each target patch over (p1 p2 c) with unbiased variance.
@@ -163,6 +179,14 @@ size_t mmae_masked_loss_workspace_bytes(int B, int C, int H, int W, int patch);
 int mmae_masked_loss(int kind, int norm_pix, const void* pred, int pred_is_bf16, const float* target, const int64_t* mask,
                      int B, int C, int H, int W, int patch, float* loss, void* d_pred, void* workspace,
                      size_t workspace_bytes, mmae_stream_t stream);
+
+/* Masked cross entropy over a class map (multimae/criterion.py:39-65): logits bf16 or f32 [B,C,H,W], target i64 [B,H,W]
+ * (-100 = ignored pixel), mask i64 [B, (H/patch)*(W/patch)] or NULL (plain mean), patch = patch_size / stride.
+ * Writes the f32 scalar loss and, if d_logits != NULL, its gradient in the logits' dtype. */
+size_t mmae_masked_ce_workspace_bytes(int B, int H, int W);
+int mmae_masked_ce(const void* logits, int logits_is_bf16, const int64_t* target, const int64_t* mask, int B, int C, int H,
+                   int W, int patch, float label_smoothing, float* loss, void* d_logits, void* workspace,
+                   size_t workspace_bytes, mmae_stream_t stream);
 
 /* ---- optimiser step over flat buffers (AdamW; run_pretraining_multimae_v2.py:339-344) -----------
  * p, g, m, v are f32 [n]; elements [0, n_decay) use weight_decay, the rest none.

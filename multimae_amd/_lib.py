@@ -17,7 +17,7 @@ SIGNATURES = {
     "mmae_gemm_nt": (_i, [_i, _p, _l, _p, _l, _i, _i, _i, _p, _p, _l, _p, _p, _l, _p]),
     "mmae_gemm_nt_set_variant": (None, [_i]),
     "mmae_patch_embed_gemm": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _p, _l, _p]),
-    "mmae_unpatchify_gemm": (_i, [_p, _l, _p, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p]),
+    "mmae_unpatchify_gemm": (_i, [_p, _l, _p, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mmae_gemm_tn_workspace_bytes": (_z, [_i, _i, _i]),
     "mmae_gemm_tn": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _i, _p, _i, _p, _z, _p]),
     "mmae_colsum_workspace_bytes": (_z, [_i, _i]),
@@ -29,7 +29,8 @@ SIGNATURES = {
     "mmae_attn_bwd_workspace_bytes": (_z, [_i, _i, _i]),
     "mmae_attn_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _p, _l, _p, _p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _i, _f, _p, _z, _p]),
     "mmae_mask_generate": (_i, [_p, _p, _p, C.POINTER(_i), _i, _i, _i, _p, _p, _p, _p, _p, _p]),
-    "mmae_pack_patches": (_i, [C.POINTER(_p), C.POINTER(_i), _i, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
+    "mmae_pack_patches": (_i, [C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_p), C.POINTER(_i), _i, _i, _i, _i, _p, _i,
+                                _p, _i, _p]),
     "mmae_build_token_table": (_i, [C.POINTER(_p), C.POINTER(_p), _i, _i, _i, _p, _p]),
     "mmae_append_global": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mmae_embed_bwd_reduce": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, C.POINTER(_p), _p, _p]),
@@ -37,8 +38,12 @@ SIGNATURES = {
     "mmae_decoder_assemble_bwd_workspace_bytes": (_z, [_i, _i, _i]),
     "mmae_decoder_assemble_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, C.POINTER(_p), _p, _z, _p]),
     "mmae_build_decoder_emb": (_i, [C.POINTER(_p), _p, _i, _i, _i, _p, _p]),
-    "mmae_patchify_bf16": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "mmae_patchify_bf16": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "mmae_class_emb_bwd_workspace_bytes": (_z, [_i, _i]),
+    "mmae_class_emb_bwd": (_i, [_p, _l, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _z, _p]),
     "mmae_masked_loss_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "mmae_masked_ce_workspace_bytes": (_z, [_i, _i, _i]),
+    "mmae_masked_ce": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _z, _p]),
     "mmae_masked_loss": (_i, [_i, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "mmae_adamw_flat": (_i, [_p, _p, _p, _p, _l, _l, _f, _f, _f, _f, _f, _i, _f, _p, _p]),
     "mmae_sumsq": (_i, [_p, _l, _p, _p, _z, _p]),

@@ -3,14 +3,17 @@
 from functools import partial
 from typing import Dict, Sequence
 
-from .criterion import MaskedL1Loss, MaskedMSELoss
-from .input_adapters import PatchedInputAdapter
+from .criterion import MaskedCrossEntropyLoss, MaskedL1Loss, MaskedMSELoss
+from .input_adapters import PatchedInputAdapter, SemSegInputAdapter
 from .multimae import create_model
 from .output_adapters import SpatialOutputAdapter
 
 DOMAIN_CONF = {
     "rgb": {"channels": 3, "stride_level": 1, "loss": MaskedMSELoss},
     "depth": {"channels": 1, "stride_level": 1, "loss": MaskedL1Loss},
+    # class map at a quarter of the image resolution; 133 COCO panoptic classes, 64-wide class embedding
+    # (run_pretraining_multimae.py:72-85 of the reference)
+    "semseg": {"num_classes": 133, "dim_class_emb": 64, "stride_level": 4, "loss": MaskedCrossEntropyLoss},
 }
 
 
@@ -18,11 +21,18 @@ def build_multimae(model: str = "pretrain_multimae_base", in_domains: Sequence[s
                    out_domains: Sequence[str] = ("rgb", "depth"), patch_size: int = 16, image_size: int = 224,
                    decoder_dim: int = 256, decoder_depth: int = 2, decoder_num_heads: int = 8,
                    extra_norm_pix_loss: bool = True, num_global_tokens: int = 1, **model_kwargs):
-    ia = {d: PatchedInputAdapter(num_channels=DOMAIN_CONF[d]["channels"], stride_level=DOMAIN_CONF[d]["stride_level"],
-                                 patch_size_full=patch_size, image_size=image_size) for d in in_domains}
+    def inp(d):
+        conf = DOMAIN_CONF[d]
+        if "num_classes" in conf:
+            return SemSegInputAdapter(num_classes=conf["num_classes"], dim_class_emb=conf["dim_class_emb"], interpolate_class_emb=False,
+                                      stride_level=conf["stride_level"], patch_size_full=patch_size, image_size=image_size)
+        return PatchedInputAdapter(num_channels=conf["channels"], stride_level=conf["stride_level"], patch_size_full=patch_size,
+                                   image_size=image_size)
+    ia = {d: inp(d) for d in in_domains}
 
     def dec(d, task):
-        return SpatialOutputAdapter(num_channels=DOMAIN_CONF[d]["channels"], stride_level=DOMAIN_CONF[d]["stride_level"],
+        return SpatialOutputAdapter(num_channels=DOMAIN_CONF[d].get("channels", DOMAIN_CONF[d].get("num_classes")),
+                                    stride_level=DOMAIN_CONF[d]["stride_level"],
                                     patch_size_full=patch_size, dim_tokens=decoder_dim, depth=decoder_depth,
                                     num_heads=decoder_num_heads, use_task_queries=True, task=task,
                                     context_tasks=list(in_domains), use_xattn=True, image_size=image_size)

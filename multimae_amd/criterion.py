@@ -35,3 +35,22 @@ class MaskedMSELoss(_MaskedPixelLoss):
 class MaskedL1Loss(_MaskedPixelLoss):
     """Reference: multimae/criterion.py:133-195."""
     kind = 1
+
+
+class MaskedCrossEntropyLoss(nn.Module):
+    """Reference: multimae/criterion.py:23-65.  input [B,C,H,W] logits (fp32 or bf16), target int64 [B,H,W],
+    mask [B, (H/scale)*(W/scale)] with scale = patch_size // stride.  As with the pixel losses, an all-zero mask
+    yields an fp32 zero (the reference returns an int64 zero)."""
+
+    def __init__(self, patch_size: int = 16, stride: int = 1, label_smoothing: float = 0.0):
+        super().__init__()
+        self.patch_size = patch_size
+        self.stride = stride
+        self.scale_factor = patch_size // stride
+        self.label_smoothing = label_smoothing
+
+    def forward(self, input, target, mask=None):
+        if mask is not None and mask.dtype != torch.int64:
+            mask = mask.to(torch.int64)
+        return Fn.MaskedCEFn.apply(input, target.to(torch.int64), None if mask is None else mask.contiguous(),
+                                   self.scale_factor, float(self.label_smoothing))

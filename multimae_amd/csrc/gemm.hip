@@ -22,7 +22,7 @@ enum {
     EPI_DGELU = 3,     // out bf16 = acc * gelu'(aux_bf16)
     EPI_F32 = 4,       // out f32 = acc (+bias)
     EPI_TOKENS = 5,    // out f32[row_map(m)] = acc + add_tab[add_idx[m]]   (patch embed)
-    EPI_UNPATCH = 6,   // out bf16 image[b,c,nh*P+ph,nw*P+pw] = acc + bias   (out_proj)
+    EPI_UNPATCH = 6,   // out bf16 / f32 image[b,c,nh*P+ph,nw*P+pw] = acc + bias   (out_proj)
 };
 
 struct GemmNT {
@@ -35,7 +35,7 @@ struct GemmNT {
     const void* aux; long ldaux;
     int seg_in, seg_out;        // EPI_TOKENS: out row = (m / seg_in) * seg_out + m % seg_in
     const int* add_idx; const float* add_tab;
-    int C, P, NH, NW;           // EPI_UNPATCH
+    int C, P, NH, NW, out_f32;  // EPI_UNPATCH
 };
 
 // Stores one wave's 64x64 accumulator block: (acc[2u][mi], acc[2u+1][mi]) = C[m = mw + mi*16 + fr][n = nw + 32*u + 8*fq + 0..7]
@@ -103,13 +103,28 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
                 *(f32x4*)op = (f32x4){v[0] + t0[0], v[1] + t0[1], v[2] + t0[2], v[3] + t0[3]};
                 *(f32x4*)(op + 4) = (f32x4){v[4] + t1[0], v[5] + t1[1], v[6] + t1[2], v[7] + t1[3]};
             } else if (EPI == EPI_UNPATCH) {
+                // the 8 columns are two runs of 4 pixels; each run stays inside one patch row because P % 4 == 0
                 const int pp = p.P * p.P;
-                const int c = n / pp, rem = n - c * pp, ph = rem / p.P, pw = rem - ph * p.P;
                 const long H = (long)p.NH * p.P, Wd = (long)p.NW * p.P;
-                bf16x8 o;
+                if (!p.out_f32 && (p.P & 7) == 0) {  // one 16-byte store
+                    const int c = n / pp, rem = n - c * pp, ph = rem / p.P, pw = rem - ph * p.P;
+                    bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-                *(bf16x8*)((bf16*)p.out + (((long)ib * p.C + c) * H + inh * p.P + ph) * Wd + inw * p.P + pw) = o;
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                    *(bf16x8*)((bf16*)p.out + (((long)ib * p.C + c) * H + inh * p.P + ph) * Wd + inw * p.P + pw) = o;
+                    continue;
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int nn = n + 4 * h;
+                    const int c = nn / pp, rem = nn - c * pp, ph = rem / p.P, pw = rem - ph * p.P;
+                    const long o = (((long)ib * p.C + c) * H + inh * p.P + ph) * Wd + inw * p.P + pw;
+                    if (p.out_f32) {
+                        *(f32x4*)((float*)p.out + o) = (f32x4){v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+                    } else {
+                        *(bf16x4*)((bf16*)p.out + o) = (bf16x4){(bf16)v[4 * h], (bf16)v[4 * h + 1], (bf16)v[4 * h + 2], (bf16)v[4 * h + 3]};
+                    }
+                }
             }
         }
     }
@@ -597,14 +612,14 @@ extern "C" int mmae_patch_embed_gemm(const void* A, const void* W, int M, int N,
 }
 
 extern "C" int mmae_unpatchify_gemm(const void* A, long lda, const void* W, int M, int N, int K, const float* bias,
-                                    void* out_image, int C, int P, int NH, int NW, hipStream_t stream) {
+                                    void* out_image, int out_is_f32, int C, int P, int NH, int NW, hipStream_t stream) {
     int rc = check_nt(A, lda, W, K, M, N, K, out_image);
     if (rc) return rc;
-    MMAE_REQUIRE(N == C * P * P && P % 8 == 0 && M % (NH * NW) == 0, MMAE_ESHAPE,
-                 "unpatchify_gemm: N=%d must equal C*P*P (C=%d P=%d) and M=%d a multiple of NH*NW", N, C, P, M);
+    MMAE_REQUIRE(N == C * P * P && P % 4 == 0 && M % (NH * NW) == 0, MMAE_ESHAPE,
+                 "unpatchify_gemm: N=%d must equal C*P*P (C=%d, P=%d a multiple of 4) and M=%d a multiple of NH*NW", N, C, P, M);
     GemmNT p = {};
     p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = K; p.M = M; p.N = N; p.K = K;
-    p.bias = bias; p.out = out_image; p.C = C; p.P = P; p.NH = NH; p.NW = NW;
+    p.bias = bias; p.out = out_image; p.C = C; p.P = P; p.NH = NH; p.NW = NW; p.out_f32 = out_is_f32;
     return launch_nt<EPI_UNPATCH>(p, stream);
 }
 

@@ -179,3 +179,115 @@ extern "C" int mmae_masked_loss(int kind, int norm_pix, const void* pred, int pr
     MMAE_CHECK_LAUNCH("loss_final");
     return MMAE_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Masked cross entropy over a class map (multimae/criterion.py:39-65 of the reference): per-pixel
+//   ce = (1 - eps) * (lse - x_target) + eps * (lse - mean_c x_c)          (eps = label smoothing; 0 for target == -100)
+// masked mean per sample over the pixels of masked patches, then mean over the samples that have any (nanmean).
+// One thread per pixel; classes are strided by H*W so each class step is a coalesced row of pixels.  The second sweep
+// (softmax - target distribution, scaled) re-reads the logits, mostly from L2.
+// ---------------------------------------------------------------------------------------------
+struct CeArgs {
+    const void* logits; const int64_t* target; const int64_t* mask;
+    int B, C, H, W, P, nh, nw, nblk;
+    float eps;
+    float* nmask; float* perr; float* loss; void* d_logits;
+};
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void ce_main_kernel(CeArgs a) {
+    __shared__ float red[16];
+    __shared__ float s_nvalid;
+    const int b = blockIdx.y;
+    const long HW = (long)a.H * a.W;
+    const long px = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = px < HW;
+    if (threadIdx.x == 0) {
+        float nv = 0.f;
+        for (int i = 0; i < a.B; ++i) nv += a.nmask[i] > 0.f ? 1.f : 0.f;
+        s_nvalid = nv;
+    }
+    __syncthreads();
+    float e = 0.f;
+    if (live) {
+        const int y = (int)(px / a.W), x = (int)(px - (long)y * a.W);
+        const float mk = a.mask ? (float)a.mask[(long)b * a.nh * a.nw + (y / a.P) * a.nw + x / a.P] : 1.f;
+        const long t = a.target[(long)b * HW + px];
+        const bool ignored = t == -100;
+        const long base = (long)b * a.C * HW + px;
+        auto ld = [&](int c) -> float {
+            return BF16 ? (float)((const bf16*)a.logits)[base + (long)c * HW] : ((const float*)a.logits)[base + (long)c * HW];
+        };
+        float m = -INFINITY, s = 0.f, sumx = 0.f, xt = 0.f;
+        for (int c = 0; c < a.C; ++c) {
+            const float v = ld(c);
+            sumx += v;
+            if (c == t) xt = v;
+            if (v > m) { s = s * __expf(m - v) + 1.f; m = v; } else { s += __expf(v - m); }
+        }
+        const float lse = m + logf(s);
+        const float ce = ignored ? 0.f : (1.f - a.eps) * (lse - xt) + a.eps * (lse - sumx / (float)a.C);
+        e = ce * mk;
+        if (a.d_logits) {
+            const float nm = a.nmask[b];
+            // 1 / (P*P * nmask_b * nvalid); 0 * inf = NaN for a sample without masked tokens (as the reference's autograd)
+            float g = s_nvalid > 0.f ? (nm > 0.f ? 1.f / s_nvalid : 0.f) * (1.0f / ((float)(a.P * a.P) * nm)) * mk : 0.f;
+            if (ignored) g = 0.f;
+            const float uni = a.eps / (float)a.C;
+            for (int c = 0; c < a.C; ++c) {
+                const float p = __expf(ld(c) - lse);
+                const float d = (p - uni - (c == t ? 1.f - a.eps : 0.f)) * g;
+                if (BF16) ((bf16*)a.d_logits)[base + (long)c * HW] = (bf16)d;
+                else ((float*)a.d_logits)[base + (long)c * HW] = d;
+            }
+        }
+    }
+    e = block_sum(e, red);
+    if (threadIdx.x == 0) a.perr[(long)b * a.nblk + blockIdx.x] = e;
+}
+
+__global__ void ce_final_kernel(CeArgs a) {
+    __shared__ float red[16];
+    float tot = 0.f, cnt = 0.f;
+    for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
+        const float nm = a.nmask[b];
+        if (nm > 0.f) {
+            float s = 0.f;
+            for (int i = 0; i < a.nblk; ++i) s += a.perr[(long)b * a.nblk + i];
+            tot += s / ((float)(a.P * a.P) * nm);
+            cnt += 1.f;
+        }
+    }
+    tot = block_sum(tot, red);
+    cnt = block_sum(cnt, red);
+    if (threadIdx.x == 0) a.loss[0] = cnt > 0.f ? tot / cnt : 0.f;
+}
+
+extern "C" size_t mmae_masked_ce_workspace_bytes(int B, int H, int W) {
+    return (size_t)B * sizeof(float) * (1 + (size_t)(((long)H * W + 255) / 256));
+}
+
+extern "C" int mmae_masked_ce(const void* logits, int logits_is_bf16, const int64_t* target, const int64_t* mask, int B, int C,
+                              int H, int W, int patch, float label_smoothing, float* loss, void* d_logits, void* workspace,
+                              size_t workspace_bytes, hipStream_t stream) {
+    MMAE_REQUIRE(logits && target && loss && workspace, MMAE_EINVAL, "masked_ce: null pointer");
+    MMAE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, MMAE_ESHAPE, "masked_ce: empty input");
+    if (!mask) patch = 1;  // plain mean over all pixels
+    MMAE_REQUIRE(patch >= 1 && H % patch == 0 && W % patch == 0, MMAE_ESHAPE, "masked_ce: map %dx%d must be a multiple of the patch %d", H, W, patch);
+    MMAE_REQUIRE(label_smoothing >= 0.f && label_smoothing <= 1.f, MMAE_EINVAL, "masked_ce: label_smoothing %f", label_smoothing);
+    MMAE_REQUIRE(workspace_bytes >= mmae_masked_ce_workspace_bytes(B, H, W), MMAE_EWORKSPACE, "masked_ce: workspace too small");
+    CeArgs a = {};
+    a.logits = logits; a.target = target; a.mask = mask; a.B = B; a.C = C; a.H = H; a.W = W; a.P = patch;
+    a.nh = H / patch; a.nw = W / patch; a.nblk = (int)(((long)H * W + 255) / 256); a.eps = label_smoothing;
+    a.nmask = (float*)workspace; a.perr = a.nmask + B; a.loss = loss; a.d_logits = d_logits;
+    LossArgs c = {};
+    c.mask = mask; c.nh = a.nh; c.nw = a.nw; c.nmask = a.nmask;
+    hipLaunchKernelGGL(loss_count_kernel, dim3(B), dim3(64), 0, stream, c);
+    MMAE_CHECK_LAUNCH("ce_count");
+    if (logits_is_bf16) hipLaunchKernelGGL(ce_main_kernel<true>, dim3(a.nblk, B), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(ce_main_kernel<false>, dim3(a.nblk, B), dim3(256), 0, stream, a);
+    MMAE_CHECK_LAUNCH("ce_main");
+    hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(256), 0, stream, a);
+    MMAE_CHECK_LAUNCH("ce_final");
+    return MMAE_OK;
+}

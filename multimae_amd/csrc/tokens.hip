@@ -8,12 +8,17 @@
 // pack the kept patches:  row (b*k + j) of A[B*k, Ktot] (bf16) =
 //   [ zeros | patch of token ids_keep[b,j] in (c, ph, pw) order at its domain's column block | zeros | one-hot(domain) | zeros ]
 // The trailing one-hot columns (at Kpatch + t) make the weight-gradient GEMM also produce the per-domain bias gradient.
+// Every domain has the same NH x NW token grid; its patch edge P_t (and so its image size NH*P_t x NW*P_t) is its own.
+// A class-map domain (class_emb != null) holds int64 class ids; its "pixels" are rows of the class-embedding table.
 // ---------------------------------------------------------------------------------------------
 struct PackArgs {
-    const float* img[TOK_MAX_TASKS];
+    const void* img[TOK_MAX_TASKS];
+    const float* class_emb[TOK_MAX_TASKS];
+    int ncls[TOK_MAX_TASKS];
     int chan[TOK_MAX_TASKS];
+    int patch[TOK_MAX_TASKS];
     int koff[TOK_MAX_TASKS + 1];
-    int T, B, H, W, P, k, Ktot, ntok, nw;
+    int T, B, k, Ktot, ntok, nw;
     const int* ids_keep;
     bf16* out;
 };
@@ -23,9 +28,11 @@ __global__ __launch_bounds__(128) void pack_patches_kernel(PackArgs a) {
     const int b = row / a.k;
     const int id = a.ids_keep[row];
     const int t = id / a.ntok, pos = id - t * a.ntok;
-    const int ph0 = (pos / a.nw) * a.P, pw0 = (pos % a.nw) * a.P;
-    const int pp = a.P * a.P;
+    const int P = a.patch[t], pp = P * P;
+    const int H = (a.ntok / a.nw) * P, W = a.nw * P;
+    const int ph0 = (pos / a.nw) * P, pw0 = (pos % a.nw) * P;
     const int Kpatch = a.koff[a.T];
+    const float* emb = a.class_emb[t];
     bf16* orow = a.out + (long)row * a.Ktot;
     for (int g = threadIdx.x; g < a.Ktot / 8; g += blockDim.x) {
         const int kk = g * 8;
@@ -33,11 +40,25 @@ __global__ __launch_bounds__(128) void pack_patches_kernel(PackArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16)0.f;
         if (kk >= a.koff[t] && kk < a.koff[t + 1]) {
-            const int l = kk - a.koff[t];
-            const int c = l / pp, rem = l - c * pp, ph = rem / a.P, pw = rem - ph * a.P;
-            const float* src = a.img[t] + (((long)b * a.chan[t] + c) * a.H + ph0 + ph) * a.W + pw0 + pw;
-            const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
-            o = (bf16x8){(bf16)v0[0], (bf16)v0[1], (bf16)v0[2], (bf16)v0[3], (bf16)v1[0], (bf16)v1[1], (bf16)v1[2], (bf16)v1[3]};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // two runs of 4 pixels, each inside one patch row (P % 4 == 0)
+                const int l = kk - a.koff[t] + 4 * h;
+                const int c = l / pp, rem = l - c * pp, ph = rem / P, pw = rem - ph * P;
+                f32x4 v;
+                if (emb) {
+                    const int64_t* cm = (const int64_t*)a.img[t] + ((long)b * H + ph0 + ph) * W + pw0 + pw;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        long cls = cm[e];
+                        cls = cls < 0 ? 0 : (cls >= a.ncls[t] ? a.ncls[t] - 1 : cls);  // out-of-range ids are clamped, never read out of bounds
+                        v[e] = emb[cls * a.chan[t] + c];
+                    }
+                } else {
+                    v = *(const f32x4*)((const float*)a.img[t] + (((long)b * a.chan[t] + c) * H + ph0 + ph) * W + pw0 + pw);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[4 * h + e] = (bf16)v[e];
+            }
         } else if (kk == Kpatch) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16)(e == t ? 1.f : 0.f);
@@ -46,24 +67,133 @@ __global__ __launch_bounds__(128) void pack_patches_kernel(PackArgs a) {
     }
 }
 
-extern "C" int mmae_pack_patches(const float* const* images_host, const int* channels_host, int T, int B, int H, int W, int P,
+extern "C" int mmae_pack_patches(const void* const* images_host, const int* channels_host, const int* patch_host,
+                                 const float* const* class_emb_host, const int* num_classes_host, int T, int B, int NH, int NW,
                                  const int* ids_keep_i32, int k, void* out_bf16, int Ktot, hipStream_t stream) {
-    MMAE_REQUIRE(images_host && channels_host && ids_keep_i32 && out_bf16, MMAE_EINVAL, "pack_patches: null pointer");
-    MMAE_REQUIRE(T >= 1 && T <= TOK_MAX_TASKS, MMAE_ESHAPE, "pack_patches: T=%d", T);
-    MMAE_REQUIRE(P % 8 == 0 && H % P == 0 && W % P == 0 && W % 4 == 0, MMAE_ESHAPE, "pack_patches: patch %d must be a multiple of 8 and divide %dx%d", P, H, W);
+    MMAE_REQUIRE(images_host && channels_host && patch_host && ids_keep_i32 && out_bf16, MMAE_EINVAL, "pack_patches: null pointer");
+    MMAE_REQUIRE(T >= 1 && T <= TOK_MAX_TASKS && NH > 0 && NW > 0, MMAE_ESHAPE, "pack_patches: T=%d grid %dx%d", T, NH, NW);
     if (B * k == 0) return MMAE_OK;
     PackArgs a = {};
     a.koff[0] = 0;
     for (int t = 0; t < T; ++t) {
         MMAE_REQUIRE(images_host[t], MMAE_EINVAL, "pack_patches: image %d is null", t);
-        a.img[t] = images_host[t]; a.chan[t] = channels_host[t];
-        a.koff[t + 1] = a.koff[t] + channels_host[t] * P * P;
+        MMAE_REQUIRE(patch_host[t] >= 4 && patch_host[t] % 4 == 0 && channels_host[t] > 0, MMAE_ESHAPE,
+                     "pack_patches: patch edge %d of domain %d must be a multiple of 4", patch_host[t], t);
+        a.img[t] = images_host[t]; a.chan[t] = channels_host[t]; a.patch[t] = patch_host[t];
+        a.class_emb[t] = class_emb_host ? class_emb_host[t] : nullptr;
+        a.ncls[t] = (a.class_emb[t] && num_classes_host) ? num_classes_host[t] : 0;
+        MMAE_REQUIRE(!a.class_emb[t] || a.ncls[t] > 0, MMAE_EINVAL, "pack_patches: class-map domain %d needs its class count", t);
+        a.koff[t + 1] = a.koff[t] + channels_host[t] * patch_host[t] * patch_host[t];
     }
     MMAE_REQUIRE(Ktot % 64 == 0 && Ktot >= a.koff[T] + 8, MMAE_ESHAPE, "pack_patches: Ktot=%d must be a multiple of 64 and >= %d", Ktot, a.koff[T] + 8);
-    a.T = T; a.B = B; a.H = H; a.W = W; a.P = P; a.k = k; a.Ktot = Ktot; a.nw = W / P; a.ntok = (H / P) * (W / P);
+    a.T = T; a.B = B; a.k = k; a.Ktot = Ktot; a.nw = NW; a.ntok = NH * NW;
     a.ids_keep = ids_keep_i32; a.out = (bf16*)out_bf16;
     hipLaunchKernelGGL(pack_patches_kernel, dim3(B * k), dim3(128), 0, stream, a);
     MMAE_CHECK_LAUNCH("pack_patches");
+    return MMAE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// class-embedding gradient of a class-map domain:
+//   d_emb[cls, c] = sum over kept tokens of the domain, over their P*P pixels with class id cls, of dA[row, (c, ph, pw)]
+// where dA = d_tokens * W_proj is the gradient of the packed patch rows.  No float atomics: thread (c, g) owns column c of
+// private table g in LDS and walks rows g, g+G, ... of its block's row range in order; tables, blocks and the final sum are
+// added in a fixed order, so the result is bitwise reproducible.
+// ---------------------------------------------------------------------------------------------
+struct ClsBwdArgs {
+    const bf16* dA; long ldd;
+    const int64_t* cmap; const int* ids_keep;
+    int M, k, tok_start, ntok, nw, P, ncls, dim, G, rows_per_block;
+    float* part;  // [nblocks][ncls][dim]
+};
+__global__ void class_emb_bwd_kernel(ClsBwdArgs a) {
+    extern __shared__ float tab[];  // [G][ncls][dim]
+    const int nthr = blockDim.x;
+    const int tsize = a.ncls * a.dim;
+    for (int i = threadIdx.x; i < a.G * tsize; i += nthr) tab[i] = 0.f;
+    __syncthreads();
+    const int c = threadIdx.x % a.dim, g = threadIdx.x / a.dim;
+    const int pp = a.P * a.P;
+    const int H = (a.ntok / a.nw) * a.P, W = a.nw * a.P;
+    const int r0 = blockIdx.x * a.rows_per_block;
+    const int r1 = min(a.M, r0 + a.rows_per_block);
+    float* mine = tab + (long)g * tsize;
+    for (int row = r0 + g; row < r1; row += a.G) {
+        const int id = a.ids_keep[row] - a.tok_start;
+        if (id < 0 || id >= a.ntok) continue;
+        const int b = row / a.k;
+        const int ph0 = (id / a.nw) * a.P, pw0 = (id % a.nw) * a.P;
+        const bf16* src = a.dA + (long)row * a.ldd + (long)c * pp;
+        for (int q = 0; q < pp; q += 4) {
+            const int ph = q / a.P, pw = q - ph * a.P;
+            const bf16x4 v = *(const bf16x4*)(src + q);
+            const int64_t* cm = a.cmap + ((long)b * H + ph0 + ph) * W + pw0 + pw;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                long cls = cm[e];
+                cls = cls < 0 ? 0 : (cls >= a.ncls ? a.ncls - 1 : cls);
+                mine[cls * a.dim + c] += (float)v[e];
+            }
+        }
+    }
+    __syncthreads();
+    float* out = a.part + (long)blockIdx.x * tsize;
+    for (int i = threadIdx.x; i < tsize; i += nthr) {
+        float s = 0.f;
+        for (int q = 0; q < a.G; ++q) s += tab[(long)q * tsize + i];
+        out[i] = s;
+    }
+}
+__global__ void class_emb_reduce_kernel(const float* __restrict__ part, int nblocks, int n, float* __restrict__ d_emb, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[(long)b * n + i];
+    d_emb[i] = accumulate ? d_emb[i] + s : s;
+}
+
+#define CLS_BWD_BLOCKS 512
+#define CLS_BWD_LDS (152 * 1024)
+extern "C" size_t mmae_class_emb_bwd_workspace_bytes(int num_classes, int dim_emb) {
+    return (size_t)CLS_BWD_BLOCKS * num_classes * dim_emb * sizeof(float);
+}
+extern "C" int mmae_class_emb_bwd(const void* dA_bf16, long ldd, const int64_t* class_map, const int* ids_keep_i32, int B, int k,
+                                  int tok_start, int NH, int NW, int P, int num_classes, int dim_emb, float* d_emb, int accumulate,
+                                  void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    MMAE_REQUIRE(dA_bf16 && class_map && ids_keep_i32 && d_emb && workspace, MMAE_EINVAL, "class_emb_bwd: null pointer");
+    MMAE_REQUIRE(P >= 4 && P % 4 == 0 && dim_emb >= 1 && dim_emb <= 1024 && num_classes >= 1 && ldd >= (long)dim_emb * P * P && ldd % 4 == 0 &&
+                 (uintptr_t)dA_bf16 % 8 == 0, MMAE_ESHAPE, "class_emb_bwd: bad shape (P=%d dim=%d classes=%d ldd=%ld)", P, dim_emb, num_classes, ldd);
+    const size_t tbytes = (size_t)num_classes * dim_emb * sizeof(float);
+    MMAE_REQUIRE(tbytes <= CLS_BWD_LDS, MMAE_ESHAPE, "class_emb_bwd: table %d x %d does not fit LDS", num_classes, dim_emb);
+    MMAE_REQUIRE(workspace_bytes >= mmae_class_emb_bwd_workspace_bytes(num_classes, dim_emb), MMAE_EWORKSPACE, "class_emb_bwd: workspace too small");
+    const int M = B * k;
+    const int n = num_classes * dim_emb;
+    if (M == 0) {
+        if (!accumulate) { hipError_t e = hipMemsetAsync(d_emb, 0, tbytes, stream); MMAE_REQUIRE(e == hipSuccess, MMAE_ELAUNCH, "class_emb_bwd: memset failed"); }
+        return MMAE_OK;
+    }
+    int G = (int)(CLS_BWD_LDS / tbytes);
+    if (G > 4) G = 4;
+    if (G * dim_emb > 1024) G = 1024 / dim_emb;
+    if (G < 1) G = 1;
+    ClsBwdArgs a = {};
+    a.dA = (const bf16*)dA_bf16; a.ldd = ldd; a.cmap = class_map; a.ids_keep = ids_keep_i32; a.M = M; a.k = k; a.tok_start = tok_start;
+    a.ntok = NH * NW; a.nw = NW; a.P = P; a.ncls = num_classes; a.dim = dim_emb; a.G = G;
+    a.rows_per_block = (M + CLS_BWD_BLOCKS - 1) / CLS_BWD_BLOCKS;
+    if (a.rows_per_block < 4 * G) a.rows_per_block = 4 * G;
+    const int nblocks = (M + a.rows_per_block - 1) / a.rows_per_block;
+    a.part = (float*)workspace;
+    const size_t lds = (size_t)G * tbytes;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)class_emb_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        MMAE_REQUIRE(e == hipSuccess, MMAE_ELAUNCH, "class_emb_bwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(class_emb_bwd_kernel, dim3(nblocks), dim3(G * dim_emb), lds, stream, a);
+    MMAE_CHECK_LAUNCH("class_emb_bwd");
+    hipLaunchKernelGGL(class_emb_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)workspace, nblocks, n, d_emb, accumulate);
+    MMAE_CHECK_LAUNCH("class_emb_reduce");
     return MMAE_OK;
 }
 
@@ -307,8 +437,9 @@ extern "C" int mmae_build_decoder_emb(const float* const* task_emb_host, const f
     return MMAE_OK;
 }
 
-// image bf16 [B,C,NH*P,NW*P] -> rows bf16 [B*NH*NW, C*P*P] ((c, ph, pw) inner order)
-__global__ void patchify_bf16_kernel(const bf16* __restrict__ img, int B, int C, int NH, int NW, int P, bf16* __restrict__ rows) {
+// image (bf16 or f32) [B,C,NH*P,NW*P] -> rows bf16 [B*NH*NW, C*P*P] ((c, ph, pw) inner order)
+template <bool F32IN>
+__global__ void patchify_bf16_kernel(const void* __restrict__ img, int B, int C, int NH, int NW, int P, bf16* __restrict__ rows) {
     const int g_per_row = C * P * P / 4;
     const long n_all = (long)B * NH * NW * g_per_row;
     const long H = (long)NH * P, W = (long)NW * P;
@@ -319,13 +450,23 @@ __global__ void patchify_bf16_kernel(const bf16* __restrict__ img, int B, int C,
         const int t = (int)(tok - (long)b * NH * NW);
         const int nh = t / NW, nw = t - nh * NW;
         const int n = g * 4, c = n / (P * P), rem = n - c * P * P, ph = rem / P, pw = rem - ph * P;
-        *(bf16x4*)(rows + tok * (C * P * P) + n) = *(const bf16x4*)(img + (((long)b * C + c) * H + nh * P + ph) * W + nw * P + pw);
+        const long src = (((long)b * C + c) * H + nh * P + ph) * W + nw * P + pw;
+        bf16x4 o;
+        if (F32IN) {
+            const f32x4 v = *(const f32x4*)((const float*)img + src);
+            o = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        } else {
+            o = *(const bf16x4*)((const bf16*)img + src);
+        }
+        *(bf16x4*)(rows + tok * (C * P * P) + n) = o;
     }
 }
-extern "C" int mmae_patchify_bf16(const void* image, int B, int C, int NH, int NW, int P, void* rows, hipStream_t stream) {
+extern "C" int mmae_patchify_bf16(const void* image, int image_is_f32, int B, int C, int NH, int NW, int P, void* rows,
+                                  hipStream_t stream) {
     MMAE_REQUIRE(image && rows && P % 4 == 0, MMAE_EINVAL, "patchify: bad argument");
     if (B == 0) return MMAE_OK;
-    hipLaunchKernelGGL(patchify_bf16_kernel, dim3(2048), dim3(256), 0, stream, (const bf16*)image, B, C, NH, NW, P, (bf16*)rows);
+    if (image_is_f32) hipLaunchKernelGGL(patchify_bf16_kernel<true>, dim3(2048), dim3(256), 0, stream, image, B, C, NH, NW, P, (bf16*)rows);
+    else hipLaunchKernelGGL(patchify_bf16_kernel<false>, dim3(2048), dim3(256), 0, stream, image, B, C, NH, NW, P, (bf16*)rows);
     MMAE_CHECK_LAUNCH("patchify");
     return MMAE_OK;
 }

@@ -201,22 +201,30 @@ def round_up(v: int, m: int) -> int:
 class EmbedFn(torch.autograd.Function):
     """Kept-token patch embedding: Conv2d(k=s=P) + pos-emb + gather(ids_keep) + global tokens
     (multimae/input_adapters.py:126-135, multimae/multimae.py:393-406 of the reference) -> x f32 [B, k+G, D].
-    Only the kept tokens are projected (the reference projects all of them and drops the rest)."""
+    Only the kept tokens are projected (the reference projects all of them and drops the rest).
+    A class-map domain (int64 input + class-embedding table; the SemSegInputAdapter named at
+    run_pretraining_multimae.py:72-85) is embedded while its patches are packed.
+
+    apply(keep32, patches, grid, pos_tables, global_tokens, n, *inputs[n], *proj_weights[n], *proj_biases[n], *class_embs[n])
+    with class_embs[t] = None for image domains."""
 
     @staticmethod
-    def forward(ctx, keep32, patch, pos_tables, global_tokens, n_img, *tensors):
+    def forward(ctx, keep32, patches, grid, pos_tables, global_tokens, n_img, *tensors):
         images = tensors[:n_img]
         weights = tensors[n_img:2 * n_img]
         biases = tensors[2 * n_img:3 * n_img]
+        class_embs = tensors[3 * n_img:4 * n_img]
+        nh, nw = grid
         B = images[0].shape[0]
         D = weights[0].shape[0]
         k = keep32.shape[1]
         G = global_tokens.shape[1]
-        ntok = pos_tables[0].shape[-1] * pos_tables[0].shape[-2]
+        ntok = nh * nw
         widths = [w[0].numel() for w in weights]
         kpatch = sum(widths)
         ktot = round_up(kpatch + 8, 64)
-        a = ops.pack_patches([im.contiguous() for im in images], patch, keep32, ktot)
+        a = ops.pack_patches([im.contiguous() for im in images], patches, keep32, ktot, nh, nw,
+                             [None if ce is None else ce.detach().contiguous() for ce in class_embs])
         wcat = torch.zeros((D, ktot), dtype=torch.bfloat16, device=a.device)
         off = 0
         for w, n in zip(weights, widths):
@@ -227,22 +235,32 @@ class EmbedFn(torch.autograd.Function):
         if k > 0:
             ops.patch_embed_gemm(a, wcat, keep32, tab, k, k + G, x)
         ops.append_global(global_tokens.detach().contiguous(), x, k)
-        ctx.saved = (a, widths, [w.shape for w in weights], k, n_img)
+        class_maps = [im if ce is not None else None for im, ce in zip(images, class_embs)]
+        ctx.saved = (a, widths, [w.shape for w in weights], k, n_img, keep32, class_maps, weights, patches, (nh, nw),
+                     [None if ce is None else tuple(ce.shape) for ce in class_embs])
         return x
 
     @staticmethod
     def backward(ctx, dx):
-        a, widths, wshapes, k, n_img = ctx.saved
+        a, widths, wshapes, k, n_img, keep32, class_maps, weights, patches, (nh, nw), ce_shapes = ctx.saved
         ctx.saved = None
         d_global, rows = ops.embed_bwd_reduce(dx.contiguous(), k)
         dwcat = ops.gemm_tn(rows, a)  # [D, ktot]: patch columns, then the one-hot(domain) columns = bias grads
         kpatch = sum(widths)
-        dws, dbs, off = [], [], 0
+        dws, dbs, dces, off = [], [], [], 0
         for t, (n, shp) in enumerate(zip(widths, wshapes)):
             dws.append(dwcat[:, off:off + n].reshape(shp))
             dbs.append(dwcat[:, kpatch + t].contiguous())
+            if class_maps[t] is None:
+                dces.append(None)
+            else:
+                # gradient of this domain's packed rows, then a fixed-order scatter to the embedding rows by class id
+                _, wt = bf16_weights(weights[t])
+                d_rows = ops.gemm_nt(ops.EPI_BF16, rows, wt, None)
+                ncls, cdim = ce_shapes[t]
+                dces.append(ops.class_emb_bwd(d_rows, class_maps[t].contiguous(), keep32, t * nh * nw, nh, nw, patches[t], ncls, cdim))
             off += n
-        return (None, None, None, d_global, None, *([None] * n_img), *dws, *dbs)
+        return (None, None, None, None, d_global, None, *([None] * n_img), *dws, *dbs, *dces)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -311,14 +329,15 @@ class DecoderHeadFn(torch.autograd.Function):
 
 
 class OutProjFn(torch.autograd.Function):
-    """out_proj + un-patchify (multimae/output_adapters.py:361-372 of the reference): x f32 [B,ntok,Dd] -> bf16 [B,C,H,W]."""
+    """out_proj + un-patchify (multimae/output_adapters.py:361-372 of the reference): x f32 [B,ntok,Dd] -> bf16 [B,C,H,W]
+    (f32 with out_f32: the un-rounded fp32 accumulators, for adapters listed in fp32_output_adapters)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, C_, P, NH, NW):
+    def forward(ctx, x, w, b, C_, P, NH, NW, out_f32=False):
         B, ntok, Dd = x.shape
         xb = ops.cast_bf16(x.contiguous().reshape(B * ntok, Dd))
         wb, wt = bf16_weights(w)
-        img = ops.unpatchify_gemm(xb, wb, b, B, C_, P, NH, NW)
+        img = ops.unpatchify_gemm(xb, wb, b, B, C_, P, NH, NW, out_f32=out_f32)
         ctx.saved = (xb, wt, (B, ntok, Dd, P), (w, b))
         return img
 
@@ -326,10 +345,25 @@ class OutProjFn(torch.autograd.Function):
     def backward(ctx, dimg):
         xb, wt, (B, ntok, Dd, P), (w, b) = ctx.saved
         ctx.saved = None
-        rows = ops.patchify_bf16(_bf16(dimg.contiguous()), P)
+        rows = ops.patchify_bf16(dimg.contiguous(), P)
         dx = ops.gemm_nt(ops.EPI_F32, rows, wt, None).reshape(B, ntok, Dd)
         dw, db = _lin_grads(rows, xb, w, b)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
+
+
+class MaskedCEFn(torch.autograd.Function):
+    """Masked cross entropy (multimae/criterion.py:39-65 of the reference); value and gradient from one kernel pass."""
+
+    @staticmethod
+    def forward(ctx, logits, target, mask, patch, label_smoothing):
+        loss, d_logits = ops.masked_ce(logits.contiguous(), target.contiguous(), mask, patch, label_smoothing, want_grad=True)
+        ctx.save_for_backward(d_logits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_logits,) = ctx.saved_tensors
+        return d_logits * g.to(d_logits.dtype), None, None, None, None
 
 
 class MaskedLossFn(torch.autograd.Function):

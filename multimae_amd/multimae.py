@@ -15,7 +15,7 @@ from torch.distributions.dirichlet import Dirichlet
 
 from . import functional as Fn
 from . import ops
-from .input_adapters import PatchedInputAdapter
+from .input_adapters import PatchedInputAdapter, SemSegInputAdapter
 from .multimae_utils import Block, trunc_normal_
 from .output_adapters import SpatialOutputAdapter
 
@@ -154,15 +154,22 @@ class MultiMAE(nn.Module):
                 alphas: Union[float, List[float]] = 1.0, sample_tasks_uniformly: bool = False,
                 fp32_output_adapters: List[str] = [], mask_randomness=None):
         x = {"rgb": x} if isinstance(x, torch.Tensor) else x
-        B, _, H, W = (x["rgb"] if "rgb" in x else next(iter(x.values()))).shape
         domains = [d for d in x if d in self.input_adapters]
         adapters = [self.input_adapters[d] for d in domains]
+        # full-resolution image size (reference: multimae/multimae.py:345-352, :507-510): from rgb when given, else from
+        # the first input scaled by its stride level
+        ref_d = "rgb" if "rgb" in x else domains[0]
+        B = x[ref_d].shape[0]
+        H, W = (s * getattr(self.input_adapters[ref_d], "stride_level", 1) if ref_d != "rgb" else s for s in x[ref_d].shape[-2:])
+        nh = nw = None
         for d, ad in zip(domains, adapters):
-            if not isinstance(ad, PatchedInputAdapter):
-                raise NotImplementedError(f"input adapter of '{d}': only PatchedInputAdapter feeds the fused patch-embed kernel")
-            if tuple(x[d].shape[-2:]) != (H, W) or ad.P_H != adapters[0].P_H:
-                raise NotImplementedError("all input domains must share the image size and the patch size")
-        nh, nw = adapters[0].grid(H, W)
+            if not isinstance(ad, (PatchedInputAdapter, SemSegInputAdapter)):
+                raise NotImplementedError(f"input adapter of '{d}': not one of the adapters the fused patch-embed kernel serves")
+            g = ad.grid(*x[d].shape[-2:])
+            if nh is None:
+                nh, nw = g
+            elif g != (nh, nw):
+                raise NotImplementedError("all input domains must map to the same token grid")
         device = x[domains[0]].device
         specs = OrderedDict((d, torch.empty((B, nh * nw, 0), device=device)) for d in domains)
         input_info = self.generate_input_info(specs, image_size=(H, W))
@@ -188,16 +195,18 @@ class MultiMAE(nn.Module):
             keep32, restore32 = ids_keep.to(torch.int32).contiguous(), ids_restore.to(torch.int32).contiguous()
         input_info["_ids_keep_i32"], input_info["_ids_restore_i32"] = keep32, restore32
 
-        tokens = Fn.EmbedFn.apply(keep32, adapters[0].P_H, [ad.pos_table(nh, nw) for ad in adapters], self.global_tokens,
-                                  len(domains), *[x[d] for d in domains], *[ad.proj.weight for ad in adapters],
-                                  *[ad.proj.bias for ad in adapters])
+        tokens = Fn.EmbedFn.apply(keep32, [ad.P_H for ad in adapters], (nh, nw), [ad.pos_table(nh, nw) for ad in adapters],
+                                  self.global_tokens, len(domains), *[x[d] for d in domains], *[ad.proj.weight for ad in adapters],
+                                  *[ad.proj.bias for ad in adapters], *[ad.class_table for ad in adapters])
         encoder_tokens = self.encoder(tokens)
         if self.output_adapters is None:
             return encoder_tokens, task_masks
-        if any(d in self.output_adapters for d in fp32_output_adapters):
-            raise NotImplementedError("fp32_output_adapters: the decoders have a single (bf16-operand) kernel path")
+        # Adapters listed in fp32_output_adapters (reference: multimae/multimae.py:426-436 runs them outside autocast)
+        # return their predictions as the un-rounded fp32 accumulators of out_proj; the matrix products themselves keep
+        # bf16 operands with fp32 accumulation like every other product of the step.
         preds = {d: self.output_adapters[d](encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep,
-                                            ids_restore=ids_restore) for d in self.output_adapters}
+                                            ids_restore=ids_restore, fp32_output=d in fp32_output_adapters)
+                 for d in self.output_adapters}
         return preds, task_masks
 
 

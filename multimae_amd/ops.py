@@ -246,15 +246,48 @@ def _ptr_array(ts: Sequence[Optional[torch.Tensor]]):
     return (C.c_void_p * len(ts))(*[0 if t is None else t.data_ptr() for t in ts])
 
 
-def pack_patches(images: Sequence[torch.Tensor], patch: int, ids_keep32: torch.Tensor, ktot: int):
-    B, _, H, W = images[0].shape
-    for im in images:
-        _req(im, F32, "pack_patches image")
+def pack_patches(images: Sequence[torch.Tensor], patches: Sequence[int], ids_keep32: torch.Tensor, ktot: int, nh: int, nw: int,
+                 class_embs: Optional[Sequence[Optional[torch.Tensor]]] = None):
+    """images[t]: f32 [B,C_t,nh*P_t,nw*P_t], or an int64 class map [B,nh*P_t,nw*P_t] when class_embs[t] (f32 [classes, C_t]) is given."""
+    class_embs = list(class_embs) if class_embs is not None else [None] * len(images)
+    B = images[0].shape[0]
+    chans = []
+    for im, P, ce in zip(images, patches, class_embs):
+        if ce is None:
+            _req(im, F32, "pack_patches image")
+            want = (B, im.shape[1], nh * P, nw * P)
+            chans.append(int(im.shape[1]))
+        else:
+            _req(im, torch.int64, "pack_patches class map"); _req(ce, F32, "pack_patches class_emb")
+            want = (B, nh * P, nw * P)
+            chans.append(int(ce.shape[1]))
+        if tuple(im.shape) != want:
+            raise _lib.MmaeError(f"pack_patches: input shape {tuple(im.shape)} != {want}")
     k = ids_keep32.shape[1]
     out = torch.empty((B * k, ktot), dtype=BF16, device=images[0].device)
-    chans = (C.c_int * len(images))(*[int(im.shape[1]) for im in images])
-    _lib.check(_L().mmae_pack_patches(_ptr_array(images), chans, len(images), B, H, W, patch, _ptr(ids_keep32), k, _ptr(out),
-                                      ktot, _stream()), "pack_patches")
+    T = len(images)
+    c_ch = (C.c_int * T)(*chans)
+    c_p = (C.c_int * T)(*[int(p) for p in patches])
+    c_ncls = (C.c_int * T)(*[0 if ce is None else int(ce.shape[0]) for ce in class_embs])
+    _lib.check(_L().mmae_pack_patches(_ptr_array(images), c_ch, c_p, _ptr_array(class_embs), c_ncls, T, B, nh, nw, _ptr(ids_keep32), k,
+                                      _ptr(out), ktot, _stream()), "pack_patches")
+    return out
+
+
+def class_emb_bwd(dA: torch.Tensor, class_map: torch.Tensor, ids_keep32: torch.Tensor, tok_start: int, nh: int, nw: int, P: int,
+                  num_classes: int, dim_emb: int, out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """dA: bf16 [B*k, >= dim_emb*P*P] (a column slice is fine) -> d_emb f32 [num_classes, dim_emb]."""
+    _req(class_map, torch.int64, "class_emb_bwd class map")
+    if dA.dtype != BF16 or dA.stride(-1) != 1:
+        raise _lib.MmaeError("class_emb_bwd: dA must be bf16 with unit column stride")
+    B, k = ids_keep32.shape
+    if out is None:
+        out = torch.empty((num_classes, dim_emb), dtype=F32, device=dA.device)
+        accumulate = False
+    ws = workspace(_L().mmae_class_emb_bwd_workspace_bytes(num_classes, dim_emb), dA.device)
+    _lib.check(_L().mmae_class_emb_bwd(_ptr(dA), dA.stride(0), _ptr(class_map), _ptr(ids_keep32), B, k, tok_start, nh, nw, P,
+                                       num_classes, dim_emb, _ptr(out), int(accumulate), _ptr(ws), ws.numel(), _stream()),
+               "class_emb_bwd")
     return out
 
 
@@ -327,21 +360,25 @@ def decoder_assemble_bwd(d_queries, d_context, keep32, restore32, k, G, T, ntok,
     return d_ctx, d_mask, d_task
 
 
-def unpatchify_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, C_: int, P: int, NH: int, NW: int):
+def unpatchify_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, C_: int, P: int, NH: int, NW: int,
+                    out_f32: bool = False):
     M, K, lda = _rows2d(a, "unpatchify a")
     N = w.shape[0]
-    img = torch.empty((B, C_, NH * P, NW * P), dtype=BF16, device=a.device)
+    img = torch.empty((B, C_, NH * P, NW * P), dtype=F32 if out_f32 else BF16, device=a.device)
     with _Timed("gemm_nt", 2.0 * M * N * K):
-        _lib.check(_L().mmae_unpatchify_gemm(_ptr(a), lda, _ptr(w), M, N, K, _ptr(bias), _ptr(img), C_, P, NH, NW, _stream()),
-                   "unpatchify_gemm")
+        _lib.check(_L().mmae_unpatchify_gemm(_ptr(a), lda, _ptr(w), M, N, K, _ptr(bias), _ptr(img), int(out_f32), C_, P, NH, NW,
+                                             _stream()), "unpatchify_gemm")
     return img
 
 
 def patchify_bf16(img: torch.Tensor, P: int):
-    _req(img, BF16, "patchify image")
+    """image bf16 or f32 [B,C,H,W] -> bf16 rows [B*(H/P)*(W/P), C*P*P]."""
+    if img.dtype not in (BF16, F32):
+        raise _lib.MmaeError(f"patchify: image dtype {img.dtype}")
+    _req(img, img.dtype, "patchify image")
     B, C_, H, W = img.shape
     rows = torch.empty((B * (H // P) * (W // P), C_ * P * P), dtype=BF16, device=img.device)
-    _lib.check(_L().mmae_patchify_bf16(_ptr(img), B, C_, H // P, W // P, P, _ptr(rows), _stream()), "patchify")
+    _lib.check(_L().mmae_patchify_bf16(_ptr(img), int(img.dtype == F32), B, C_, H // P, W // P, P, _ptr(rows), _stream()), "patchify")
     return rows
 
 
@@ -361,6 +398,27 @@ def masked_loss(kind: int, norm_pix: bool, pred: torch.Tensor, target: torch.Ten
     _lib.check(_L().mmae_masked_loss(kind, int(norm_pix), _ptr(pred), int(pred.dtype == BF16), _ptr(target), _ptr(mask), B, C_, H,
                                      W, patch, _ptr(loss), _ptr(d_pred), _ptr(ws), ws.numel(), _stream()), "masked_loss")
     return loss, d_pred
+
+
+def masked_ce(logits: torch.Tensor, target: torch.Tensor, mask: Optional[torch.Tensor], patch: int, label_smoothing: float = 0.0,
+              want_grad: bool = True):
+    """Returns (loss f32 scalar tensor, d_logits or None)."""
+    if logits.dtype not in (BF16, F32):
+        raise _lib.MmaeError(f"masked_ce: logits dtype {logits.dtype}")
+    _req(logits, logits.dtype, "masked_ce logits"); _req(target, torch.int64, "masked_ce target")
+    B, C_, H, W = logits.shape
+    if tuple(target.shape) != (B, H, W):
+        raise _lib.MmaeError(f"masked_ce: target shape {tuple(target.shape)} != {(B, H, W)}")
+    if mask is not None:
+        _req(mask, torch.int64, "masked_ce mask")
+        if mask.numel() != B * (H // patch) * (W // patch):
+            raise _lib.MmaeError(f"masked_ce: mask has {mask.numel()} entries, expected {B * (H // patch) * (W // patch)}")
+    loss = torch.empty((), dtype=F32, device=logits.device)
+    d_logits = torch.empty_like(logits) if want_grad else None
+    ws = workspace(_L().mmae_masked_ce_workspace_bytes(B, H, W), logits.device)
+    _lib.check(_L().mmae_masked_ce(_ptr(logits), int(logits.dtype == BF16), _ptr(target), _ptr(mask), B, C_, H, W, patch,
+                                   float(label_smoothing), _ptr(loss), _ptr(d_logits), _ptr(ws), ws.numel(), _stream()), "masked_ce")
+    return loss, d_logits
 
 
 # --------------------------------------------------------------------------------------------- optimiser

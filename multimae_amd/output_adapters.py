@@ -82,7 +82,7 @@ class SpatialOutputAdapter(nn.Module):
             return self.pos_emb
         return F.interpolate(self.pos_emb, size=(nh, nw), mode="bilinear", align_corners=False)
 
-    def forward(self, encoder_tokens: Tensor, input_info: Dict, ids_keep: Tensor, ids_restore: Tensor):
+    def forward(self, encoder_tokens: Tensor, input_info: Dict, ids_keep: Tensor, ids_restore: Tensor, fp32_output: bool = False):
         assert self.dim_tokens_enc is not None, "Need to call init(dim_tokens_enc) function first"
         H, W = input_info["image_size"]
         nh = H // (self.stride_level * self.P_H)
@@ -110,7 +110,7 @@ class SpatialOutputAdapter(nn.Module):
             self.context_norm.weight, self.context_norm.bias, d.q.weight, _b(d.q), d.kv.weight, _b(d.kv), d.proj.weight, d.proj.bias,
             self.out_norm.weight, self.out_norm.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, *embs)
         x = self.decoder_transformer(x)
-        return Fn.OutProjFn.apply(x, self.out_proj.weight, self.out_proj.bias, self.num_channels, self.P_H, nh, nw)
+        return Fn.OutProjFn.apply(x, self.out_proj.weight, self.out_proj.bias, self.num_channels, self.P_H, nh, nw, fp32_output)
 
 
 def _b(lin: nn.Linear):

@@ -47,15 +47,24 @@ def make_cfg(
     image: int = 224,
     num_global: int = 1,
     mlp_ratio: float = 4.0,
+    stride: Optional[Dict[str, int]] = None,
+    num_classes: Optional[Dict[str, int]] = None,
 ) -> dict:
-    """in_domains: name -> channels.  out_domains: name -> (channels, query task)."""
+    """in_domains: name -> channels (for a class-map domain: the class-embedding width).
+    out_domains: name -> (channels, query task).  stride: name -> stride level of a domain (input or output; default 1).
+    num_classes: name -> number of classes of a class-map input domain (its input is int64 [B, H/stride, W/stride])."""
     return dict(
         in_domains=dict(in_domains),
         out_domains={k: (int(c), str(t)) for k, (c, t) in out_domains.items()},
         dim=dim, depth=depth, heads=heads, dec_dim=dec_dim, dec_depth=dec_depth,
         dec_heads=dec_heads, patch=patch, image=image, num_global=num_global,
-        mlp_ratio=mlp_ratio,
+        mlp_ratio=mlp_ratio, stride=dict(stride or {}), num_classes=dict(num_classes or {}),
     )
+
+
+def domain_patch(cfg: dict, name: str) -> int:
+    """Patch edge in the domain's own pixels: max(1, patch_size_full // stride_level) (input_adapters.py:64-65)."""
+    return max(1, cfg["patch"] // cfg.get("stride", {}).get(name, 1))
 
 
 def vit_b_rgbd_cfg(extra_norm_pix: bool = True, image: int = 224) -> dict:
@@ -65,6 +74,24 @@ def vit_b_rgbd_cfg(extra_norm_pix: bool = True, image: int = 224) -> dict:
     if extra_norm_pix:
         out["norm_rgb"] = (3, "rgb")
     return make_cfg({"rgb": 3, "depth": 1}, out, image=image)
+
+
+def vit_b_rgbd_semseg_cfg(extra_norm_pix: bool = False, image: int = 224, num_classes: int = 133,
+                          dim_class_emb: int = 64) -> dict:
+    """ViT-B/16 RGB + depth + semantic segmentation (class map at stride 4, 133 COCO classes, 64-wide class embedding):
+    run_pretraining_multimae.py:72-85 and cfgs/pretrain/multimae-b_98_rgb+-depth-semseg_1600e.yaml of the reference."""
+    out = {"rgb": (3, "rgb"), "depth": (1, "depth"), "semseg": (num_classes, "semseg")}
+    if extra_norm_pix:
+        out["norm_rgb"] = (3, "rgb")
+    return make_cfg({"rgb": 3, "depth": 1, "semseg": dim_class_emb}, out, image=image,
+                    stride={"semseg": 4}, num_classes={"semseg": num_classes})
+
+
+def small_semseg_cfg() -> dict:
+    """small_cfg plus a class-map domain (9 classes, 8-wide class embedding, stride 4)."""
+    out = {"rgb": (3, "rgb"), "depth": (1, "depth"), "semseg": (9, "semseg")}
+    return make_cfg({"rgb": 3, "depth": 1, "semseg": 8}, out, dim=128, depth=2, heads=4, dec_dim=64,
+                    dec_depth=1, dec_heads=2, patch=16, image=64, stride={"semseg": 4}, num_classes={"semseg": 9})
 
 
 def tiny_cfg() -> dict:
@@ -142,14 +169,18 @@ def init_state(cfg: dict, seed: int = 0) -> Dict[str, Tensor]:
 
     sd["global_tokens"] = _trunc_normal((1, cfg["num_global"], D), 0.02, g)
     for name, C in cfg["in_domains"].items():
+        Pd = domain_patch(cfg, name)
         sd[f"input_adapters.{name}.pos_emb"] = sincos_posemb(n, n, D)
-        sd[f"input_adapters.{name}.proj.weight"] = _xavier(D, C * P * P, g).reshape(D, C, P, P)
-        bound = 1.0 / math.sqrt(C * P * P)  # nn.Conv2d default bias init
+        if name in cfg.get("num_classes", {}):
+            sd[f"input_adapters.{name}.class_emb.weight"] = _trunc_normal((cfg["num_classes"][name], C), 0.02, g)
+        sd[f"input_adapters.{name}.proj.weight"] = _xavier(D, C * Pd * Pd, g).reshape(D, C, Pd, Pd)
+        bound = 1.0 / math.sqrt(C * Pd * Pd)  # nn.Conv2d default bias init
         sd[f"input_adapters.{name}.proj.bias"] = torch.empty(D).uniform_(-bound, bound, generator=g)
     for i in range(cfg["depth"]):
         block(f"encoder.{i}", D, hid)
     for name, (C, _task) in cfg["out_domains"].items():
         p = f"output_adapters.{name}"
+        Po = domain_patch(cfg, name)
         for t in cfg["in_domains"]:
             sd[f"{p}.task_embeddings.{t}"] = _trunc_normal((1, 1, Dd), 0.02, g)
         sd[f"{p}.mask_token"] = torch.zeros(1, 1, Dd)
@@ -169,8 +200,8 @@ def init_state(cfg: dict, seed: int = 0) -> Dict[str, Tensor]:
         sd[f"{p}.mlp.fc2.bias"] = torch.zeros(Dd)
         for j in range(cfg["dec_depth"]):
             block(f"{p}.decoder_transformer.{j}", Dd, hid_d)
-        sd[f"{p}.out_proj.weight"] = _xavier(C * P * P, Dd, g)
-        sd[f"{p}.out_proj.bias"] = torch.zeros(C * P * P)
+        sd[f"{p}.out_proj.weight"] = _xavier(C * Po * Po, Dd, g)
+        sd[f"{p}.out_proj.bias"] = torch.zeros(C * Po * Po)
         sd[f"{p}.proj_context.weight"] = _xavier(Dd, D, g)
         sd[f"{p}.proj_context.bias"] = torch.zeros(Dd)
     return sd
@@ -287,6 +318,20 @@ def _resample(tab: Tensor, size: Tuple[int, int], mode: str) -> Tensor:
     return F.interpolate(tab, size=size, mode=mode, align_corners=False)
 
 
+def semseg_input_adapter(class_map: Tensor, sd, prefix: str, p: int) -> Tensor:
+    """Class map int64 [B,H,W] -> Embedding -> Conv2d(k=s=p) -> tokens + bilinear-resampled pos-emb.
+    The reference fork does not contain this adapter (only its call site, run_pretraining_multimae.py:72-85, and the
+    input contract at multimae/multimae.py:507-510); this follows the upstream MultiMAE definition the call-site arguments
+    (num_classes, dim_class_emb, interpolate_class_emb=False) belong to.  PARITY UNPINNED."""
+    B, H, W = class_map.shape
+    assert H % p == 0 and W % p == 0
+    emb = sd[f"{prefix}.class_emb.weight"][class_map].permute(0, 3, 1, 2)  # [B, C, H, W]
+    w = sd[f"{prefix}.proj.weight"]
+    tok = F.linear(patchify_cpp(emb, p), w.reshape(w.shape[0], -1), sd[f"{prefix}.proj.bias"])
+    pos = _resample(sd[f"{prefix}.pos_emb"], (H // p, W // p), "bilinear")
+    return tok + pos.flatten(2).transpose(1, 2)
+
+
 def input_adapter(img: Tensor, sd, prefix: str, p: int) -> Tensor:
     B, C, H, W = img.shape
     assert H % p == 0 and W % p == 0
@@ -300,10 +345,13 @@ def input_adapter(img: Tensor, sd, prefix: str, p: int) -> Tensor:
 # output adapter (multimae/output_adapters.py:195-374)
 # --------------------------------------------------------------------------
 def output_adapter(enc: Tensor, sd, prefix: str, cfg: dict, out_channels: int, task: str,
-                   ids_keep: Tensor, ids_restore: Tensor, image_hw: Tuple[int, int]) -> Tensor:
+                   ids_keep: Tensor, ids_restore: Tensor, image_hw: Tuple[int, int], patch: Optional[int] = None) -> Tensor:
+    """image_hw is the full-resolution image size; `patch` the output patch edge in the output's own pixels
+    (patch_size_full // stride_level, output_adapters.py:101-102; token grid = image // patch_size_full, :332-334)."""
     B = enc.shape[0]
-    P, G = cfg["patch"], cfg["num_global"]
-    nh, nw = image_hw[0] // P, image_hw[1] // P
+    G = cfg["num_global"]
+    nh, nw = image_hw[0] // cfg["patch"], image_hw[1] // cfg["patch"]
+    P = cfg["patch"] if patch is None else patch
     names = list(cfg["in_domains"].keys())
     n_tok = nh * nw
     total = n_tok * len(names)
@@ -342,7 +390,8 @@ def forward(sd: Dict[str, Tensor], cfg: dict, x: Dict[str, Tensor], task_samplin
     names = list(cfg["in_domains"].keys())
     first = x["rgb"] if "rgb" in x else x[names[0]]
     B, _, H, W = first.shape
-    toks = [input_adapter(x[d], sd, f"input_adapters.{d}", cfg["patch"]) for d in names]
+    toks = [semseg_input_adapter(x[d], sd, f"input_adapters.{d}", domain_patch(cfg, d)) if d in cfg.get("num_classes", {})
+            else input_adapter(x[d], sd, f"input_adapters.{d}", domain_patch(cfg, d)) for d in names]
     masks, ids_keep, ids_restore = generate_masks(task_sampling_dist, noises, noise_all, num_encoded_tokens)
     allt = torch.cat(toks, dim=1)
     D = allt.shape[-1]
@@ -354,7 +403,8 @@ def forward(sd: Dict[str, Tensor], cfg: dict, x: Dict[str, Tensor], task_samplin
     if return_encoder:
         return enc, mask_d, ids_keep, ids_restore
     preds = {
-        name: output_adapter(enc, sd, f"output_adapters.{name}", cfg, C, task, ids_keep, ids_restore, (H, W))
+        name: output_adapter(enc, sd, f"output_adapters.{name}", cfg, C, task, ids_keep, ids_restore, (H, W),
+                             patch=domain_patch(cfg, name))
         for name, (C, task) in cfg["out_domains"].items()
     }
     return preds, mask_d
@@ -439,6 +489,8 @@ def default_loss_table(cfg: dict):
             tab[name] = (masked_l1, "depth", "depth", dict(patch_size=cfg["patch"]))
         elif name == "norm_rgb":
             tab[name] = (masked_mse, "rgb", "rgb", dict(patch_size=cfg["patch"], norm_pix=True))
+        elif name == "semseg":  # run_pretraining_multimae.py:72-85: masked CE at the class map's stride
+            tab[name] = (masked_ce, "semseg", "semseg", dict(patch_size=cfg["patch"], stride=cfg["stride"].get("semseg", 1)))
         else:
             raise KeyError(name)
     return tab

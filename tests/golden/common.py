@@ -5,6 +5,20 @@ import torch
 
 from oracle import multimae_oracle as O
 
+SEMSEG_GRAD_NAMES = [
+    "global_tokens",
+    "input_adapters.semseg.class_emb.weight",
+    "input_adapters.semseg.proj.weight",
+    "input_adapters.semseg.proj.bias",
+    "input_adapters.rgb.proj.weight",
+    "encoder.0.attn.qkv.weight",
+    "output_adapters.semseg.out_proj.weight",
+    "output_adapters.semseg.out_proj.bias",
+    "output_adapters.semseg.task_embeddings.rgb",
+    "output_adapters.depth.task_embeddings.semseg",
+    "output_adapters.semseg.mask_token",
+]
+
 TINY_GRAD_NAMES = [
     "global_tokens",
     "input_adapters.depth.proj.weight",
@@ -59,7 +73,10 @@ def seeded_inputs(cfg, B, seed):
     S = cfg["image"]
     x = {}
     for d, C in cfg["in_domains"].items():
-        if d == "rgb":
+        if d in cfg.get("num_classes", {}):
+            st = cfg["stride"][d]
+            x[d] = torch.randint(0, cfg["num_classes"][d], (B, S // st, S // st), generator=g)
+        elif d == "rgb":
             x[d] = torch.randn(B, C, S, S, generator=g)
         else:
             x[d] = torch.rand(B, C, S, S, generator=g)

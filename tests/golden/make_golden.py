@@ -176,6 +176,83 @@ def gen_tiny_e2e(cfg=None, fname="tiny_e2e.npz"):
     print(fname, "ok; losses", {t: float(v) for t, v in losses.items()})
 
 
+class _ClassMapAdapter(torch.nn.Module):
+    """Stand-in for the input adapter the reference fork lacks (its call site: run_pretraining_multimae.py:72-85):
+    class map -> Embedding -> Conv2d(k=s=P) -> + pos_emb, with the parameter names class_emb / proj / pos_emb.
+    Test code written for this fixture; everything downstream of it in the fixture is the reference's own code."""
+
+    def __init__(self, num_classes, dim_class_emb, stride_level, patch_size_full, image_size):
+        super().__init__()
+        self.num_classes, self.dim_class_emb, self.stride_level = num_classes, dim_class_emb, stride_level
+        self.P = max(1, patch_size_full // stride_level)
+        self.image_size = image_size
+        self.dim_tokens = None
+
+    def init(self, dim_tokens=768):
+        self.dim_tokens = dim_tokens
+        h = self.image_size // (self.stride_level * self.P)
+        self.pos_emb = torch.nn.Parameter(build_2d_sincos_posemb(h, h, dim_tokens), requires_grad=False)
+        self.class_emb = torch.nn.Embedding(self.num_classes, self.dim_class_emb)
+        self.proj = torch.nn.Conv2d(self.dim_class_emb, dim_tokens, kernel_size=self.P, stride=self.P)
+
+    def no_weight_decay(self):
+        return {"pos_emb"}
+
+    def forward(self, x):
+        e = self.class_emb(x).permute(0, 3, 1, 2)
+        t = self.proj(e).flatten(2).transpose(1, 2)
+        pos = torch.nn.functional.interpolate(self.pos_emb, size=(x.shape[1] // self.P, x.shape[2] // self.P), mode="bilinear")
+        return t + pos.flatten(2).transpose(1, 2)
+
+
+def gen_semseg_e2e(fname="small_semseg_e2e.npz"):
+    """rgb + depth + class map (stride 4) through the reference's MultiMAE / SpatialOutputAdapter(stride_level=4) /
+    MaskedCrossEntropyLoss(16, 4); pins the three-domain masking, the stride-4 decoder output and the masked CE."""
+    cfg = O.small_semseg_cfg()
+    sd = G.perturbed_state(cfg, seed=9)
+    n_img = cfg["image"]
+    ia = {}
+    for d, C in cfg["in_domains"].items():
+        if d in cfg["num_classes"]:
+            ia[d] = _ClassMapAdapter(cfg["num_classes"][d], C, cfg["stride"][d], cfg["patch"], n_img)
+        else:
+            ia[d] = ref.PatchedInputAdapter(num_channels=C, stride_level=1, patch_size_full=cfg["patch"], image_size=n_img)
+    oa = {name: ref.SpatialOutputAdapter(num_channels=C, stride_level=cfg["stride"].get(name, 1), patch_size_full=cfg["patch"],
+                                         dim_tokens=cfg["dec_dim"], depth=cfg["dec_depth"], num_heads=cfg["dec_heads"],
+                                         use_task_queries=True, task=task, context_tasks=list(cfg["in_domains"]),
+                                         use_xattn=True, image_size=n_img)
+          for name, (C, task) in cfg["out_domains"].items()}
+    model = ref.MultiMAE(ia, oa, num_global_tokens=cfg["num_global"], dim_tokens=cfg["dim"], depth=cfg["depth"],
+                         num_heads=cfg["heads"])
+    model.load_state_dict(sd, strict=True)
+    x = G.seeded_inputs(cfg, B=2, seed=4)
+    k, seed = 12, 6
+    n = (cfg["image"] // cfg["patch"]) ** 2
+    p, noises, noise_all = replay_mask_rng(seed, 2, [n, n, n], 1.0, False)
+    G.assert_tie_free(p, noises, noise_all, k)
+    losses_fn = {"rgb": ref.MaskedMSELoss(patch_size=16, stride=1), "depth": ref.MaskedL1Loss(patch_size=16, stride=1),
+                 "semseg": ref.MaskedCrossEntropyLoss(patch_size=16, stride=4)}
+    out = {"k": np.int64(k), "p": p.numpy(), "noise_all": noise_all.numpy()}
+    for i, nz in enumerate(noises):
+        out[f"noise{i}"] = nz.numpy()
+    torch.manual_seed(seed)
+    model.zero_grad()
+    preds, masks = model(x, num_encoded_tokens=k, alphas=1.0)
+    losses = {t: losses_fn[t](preds[t].float(), x[t], mask=masks[t]) for t in preds}
+    sum(losses.values()).backward()
+    named = dict(model.named_parameters())
+    for t in preds:
+        out[f"pred_{t}"] = preds[t].detach().numpy()
+        out[f"loss_{t}"] = losses[t].detach().numpy()
+    for d in masks:
+        out[f"mask_{d}"] = masks[d].numpy().astype(np.uint8)
+    for name in G.SEMSEG_GRAD_NAMES:
+        out["grad_" + name] = named[name].grad.numpy()
+    out["grad_norm"] = torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in named.values() if p_.grad is not None)).numpy()
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, "ok; losses", {t: float(v) for t, v in losses.items()})
+
+
 def gen_losses():
     out = {}
     g = torch.Generator().manual_seed(21)
@@ -266,6 +343,11 @@ def gen_depth_std():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # regenerate only the named fixtures, e.g. `make_golden.py gen_semseg_e2e`
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
+    gen_semseg_e2e()
     gen_masks()
     gen_posemb()
     gen_tiny_e2e()

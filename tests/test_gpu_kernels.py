@@ -332,3 +332,114 @@ def test_transpose_multi_matches_torch(ops):
     ops.transpose_multi(src, dst, torch.tensor(rows, dtype=torch.int32, device="cuda"), tiles)
     for (n, k), o in zip(shapes, offs):
         assert torch.equal(dst[o:o + n * k].view(k, n), src[o:o + n * k].view(n, k).t())
+
+
+# ---------------------------------------------------------------------------------------------- config-4 pieces
+def test_masked_ce_golden(ops):
+    from tests.golden import common as G
+    z = G.load("losses.npz")
+    for tag, ls in (("ce", 0.0), ("ce_ls", 0.1), ("ce_nomask", 0.0)):
+        logits = torch.from_numpy(z[tag + "_pred"]).cuda()
+        target = torch.from_numpy(z[tag + "_target"]).cuda()
+        mask = torch.from_numpy(z[tag + "_mask"].astype(np.int64)).cuda() if (tag + "_mask") in z else None
+        loss, dl = ops.masked_ce(logits, target, mask, 4, ls)
+        ref = float(z[tag + "_loss"])
+        assert abs(loss.item() - ref) <= FP32_TOL * abs(ref), tag
+        assert rel_err(dl.cpu(), z[tag + "_dpred"]) < FP32_TOL, tag
+
+
+def test_masked_ce_full_size_vs_oracle(ops):
+    """133 classes at 56x56 (the stride-4 class map of a 224^2 image), one sample without masked tokens, ignored pixels."""
+    from oracle import multimae_oracle as O
+    B, C, S = 6, 133, 56
+    g = torch.Generator().manual_seed(11)
+    logits = torch.randn(B, C, S, S, generator=g) * 3
+    target = torch.randint(0, C, (B, S, S), generator=g)
+    target[1, :5] = -100
+    mask = (torch.rand(B, 196, generator=g) > 0.25).long()
+    mask[2] = 0
+    for ls in (0.0, 0.1):
+        lr = logits.clone().requires_grad_(True)
+        ref = O.masked_ce(lr, target, mask=mask, patch_size=16, stride=4, label_smoothing=ls)
+        ref.backward()
+        loss, dl = ops.masked_ce(logits.cuda(), target.cuda(), mask.cuda(), 4, ls)
+        assert abs(loss.item() - ref.item()) / abs(ref.item()) < FP32_TOL
+        g_hip, g_ref = dl.cpu(), lr.grad
+        assert torch.equal(g_hip.isnan(), g_ref.isnan()) and g_ref[2].isnan().all()
+        ok = ~g_ref.isnan()
+        assert rel_err(g_hip[ok], g_ref[ok]) < FP32_TOL
+    # bf16 logits, bf16 gradient; nothing masked at all -> 0 and zero gradient
+    lb = logits.cuda().bfloat16()
+    loss_b, dl_b = ops.masked_ce(lb, target.cuda(), mask.cuda(), 4, 0.0)
+    lr = lb.float().cpu().requires_grad_(True)
+    ref = O.masked_ce(lr, target, mask=mask, patch_size=16, stride=4)
+    ref.backward()
+    assert abs(loss_b.item() - ref.item()) / abs(ref.item()) < FP32_TOL and dl_b.dtype == torch.bfloat16
+    ok = ~lr.grad.isnan()
+    assert rel_err(dl_b.float().cpu()[ok], lr.grad[ok]) < 4e-3
+    loss0, dl0 = ops.masked_ce(logits.cuda(), target.cuda(), torch.zeros_like(mask).cuda(), 4, 0.0)
+    assert loss0.item() == 0.0 and dl0.abs().max().item() == 0.0
+
+
+def test_pack_patches_class_map_and_embedding_backward(ops):
+    """Class-map domain next to an image domain: packed rows = embedding rows of the kept patches; the embedding
+    gradient equals index_add of the row gradients, bitwise reproducible."""
+    torch.manual_seed(5)
+    B, nh, nw, P_img, P_cls, ncls, cdim, k = 3, 4, 4, 16, 4, 11, 8, 9
+    img = torch.randn(B, 2, nh * P_img, nw * P_img, device="cuda")
+    cmap = torch.randint(0, ncls, (B, nh * P_cls, nw * P_cls), device="cuda")
+    emb = torch.randn(ncls, cdim, device="cuda")
+    ntok = nh * nw
+    keep = torch.stack([torch.randperm(2 * ntok)[:k] for _ in range(B)]).to(torch.int32).cuda()
+    k_img, k_cls = 2 * P_img * P_img, cdim * P_cls * P_cls
+    ktot = (k_img + k_cls + 8 + 63) // 64 * 64
+    a = ops.pack_patches([img, cmap], [P_img, P_cls], keep, ktot, nh, nw, [None, emb])
+    e_img = emb[cmap].permute(0, 3, 1, 2)  # [B, cdim, H, W]
+    rows_img = img.reshape(B, 2, nh, P_img, nw, P_img).permute(0, 2, 4, 1, 3, 5).reshape(B, ntok, k_img)
+    rows_cls = e_img.reshape(B, cdim, nh, P_cls, nw, P_cls).permute(0, 2, 4, 1, 3, 5).reshape(B, ntok, k_cls)
+    want = torch.zeros(B * k, ktot, device="cuda")
+    for b in range(B):
+        for j in range(k):
+            t, pos = divmod(int(keep[b, j]), ntok)
+            if t == 0:
+                want[b * k + j, :k_img] = rows_img[b, pos]
+            else:
+                want[b * k + j, k_img:k_img + k_cls] = rows_cls[b, pos]
+            want[b * k + j, k_img + k_cls + t] = 1.0
+    assert torch.equal(a.float(), want.bfloat16().float())
+
+    d_rows = torch.randn(B * k, ktot, device="cuda").bfloat16()
+    d_cls = d_rows[:, k_img:k_img + k_cls]
+    got = ops.class_emb_bwd(d_cls, cmap, keep, ntok, nh, nw, P_cls, ncls, cdim)
+    ref = torch.zeros(ncls, cdim, dtype=torch.float64, device="cuda")
+    for b in range(B):
+        for j in range(k):
+            t, pos = divmod(int(keep[b, j]), ntok)
+            if t != 1:
+                continue
+            y0, x0 = (pos // nw) * P_cls, (pos % nw) * P_cls
+            cls = cmap[b, y0:y0 + P_cls, x0:x0 + P_cls].reshape(-1)
+            gpatch = d_cls[b * k + j].double().reshape(cdim, P_cls * P_cls)
+            ref.index_add_(0, cls, gpatch.t().contiguous())
+    assert rel_err(got.cpu(), ref.cpu()) < 1e-6
+    assert torch.equal(got, ops.class_emb_bwd(d_cls, cmap, keep, ntok, nh, nw, P_cls, ncls, cdim))
+    acc = got.clone()
+    ops.class_emb_bwd(d_cls, cmap, keep, ntok, nh, nw, P_cls, ncls, cdim, out=acc, accumulate=True)
+    assert torch.allclose(acc, 2 * got)
+
+
+def test_unpatchify_patch4_and_fp32_output(ops):
+    torch.manual_seed(9)
+    B, C, P, nh, nw, Dd = 2, 9, 4, 4, 4, 64
+    x = torch.randn(B * nh * nw, Dd, device="cuda").bfloat16()
+    w = (torch.randn(C * P * P, Dd, device="cuda") * 0.1).bfloat16()
+    bias = torch.randn(C * P * P, device="cuda")
+    ref = (x.float() @ w.float().t() + bias).reshape(B, nh, nw, C, P, P).permute(0, 3, 1, 4, 2, 5).reshape(B, C, nh * P, nw * P)
+    img32 = ops.unpatchify_gemm(x, w, bias, B, C, P, nh, nw, out_f32=True)
+    img16 = ops.unpatchify_gemm(x, w, bias, B, C, P, nh, nw)
+    assert img32.dtype == torch.float32 and rel_err(img32.cpu(), ref.cpu()) < 1e-5
+    assert img16.dtype == torch.bfloat16 and torch.equal(img16, img32.bfloat16())
+    rows = ops.patchify_bf16(img32, P)  # the adjoint layout: back to one row per token
+    back = (x.float() @ w.float().t() + bias)
+    assert torch.equal(rows, back.bfloat16()) or rel_err(rows.float().cpu(), back.cpu()) < 4e-3
+    assert torch.equal(ops.patchify_bf16(img16, P), rows)

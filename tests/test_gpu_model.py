@@ -220,3 +220,58 @@ def test_flat_bf16_weight_copies_track_the_master():
         w.mul_(1.5)
     wb, wt = Fn.bf16_weights(w)
     assert torch.equal(wb, w.detach().bfloat16()) and torch.equal(wt, w.detach().bfloat16().t())
+
+
+def _build_semseg(cfg):
+    import multimae_amd as M
+    n_img = cfg["image"]
+    ia = {}
+    for d, C in cfg["in_domains"].items():
+        if d in cfg["num_classes"]:
+            ia[d] = M.SemSegInputAdapter(num_classes=cfg["num_classes"][d], dim_class_emb=C, interpolate_class_emb=False,
+                                         stride_level=cfg["stride"][d], patch_size_full=cfg["patch"], image_size=n_img)
+        else:
+            ia[d] = M.PatchedInputAdapter(num_channels=C, stride_level=1, patch_size_full=cfg["patch"], image_size=n_img)
+    oa = {name: M.SpatialOutputAdapter(num_channels=C, stride_level=cfg["stride"].get(name, 1), patch_size_full=cfg["patch"],
+                                       dim_tokens=cfg["dec_dim"], depth=cfg["dec_depth"], num_heads=cfg["dec_heads"],
+                                       use_task_queries=True, task=task, context_tasks=list(cfg["in_domains"]), use_xattn=True,
+                                       image_size=n_img)
+          for name, (C, task) in cfg["out_domains"].items()}
+    return M.MultiMAE(ia, oa, num_global_tokens=cfg["num_global"], dim_tokens=cfg["dim"], depth=cfg["depth"], num_heads=cfg["heads"])
+
+
+def test_three_domain_semseg_model_vs_reference_golden():
+    """rgb + depth + class map at stride 4 with a masked-CE semseg decoder (fp32 logits), against the fixture produced by the
+    reference's MultiMAE / SpatialOutputAdapter / MaskedCrossEntropyLoss."""
+    import multimae_amd as M
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    z = G.load("small_semseg_e2e.npz")
+    cfg = O.small_semseg_cfg()
+    model = _build_semseg(cfg)
+    model.load_state_dict(G.perturbed_state(cfg, seed=9), strict=True)
+    model.cuda()
+    x = {d: t.cuda() for d, t in G.seeded_inputs(cfg, B=2, seed=4).items()}
+    rnd = (torch.from_numpy(z["p"]), [torch.from_numpy(z[f"noise{i}"]) for i in range(3)], torch.from_numpy(z["noise_all"]))
+    fns = {"rgb": M.MaskedMSELoss(16, 1), "depth": M.MaskedL1Loss(16, 1), "semseg": M.MaskedCrossEntropyLoss(16, 4)}
+    model.zero_grad(set_to_none=True)
+    preds, masks = model(x, num_encoded_tokens=int(z["k"]), alphas=1.0, mask_randomness=rnd, fp32_output_adapters=["semseg"])
+    assert preds["semseg"].dtype == torch.float32 and preds["rgb"].dtype == torch.bfloat16
+    losses = {t: fns[t](preds[t], x[t], mask=masks[t]) for t in preds}
+    sum(losses.values()).backward()
+    for d in masks:
+        assert np.array_equal(masks[d].cpu().numpy(), z[f"mask_{d}"].astype(np.int64)), d
+    report = {}
+    for t in preds:
+        assert preds[t].shape == z[f"pred_{t}"].shape
+        report[f"pred_{t}"] = rel_err(preds[t].float().cpu(), z[f"pred_{t}"])
+        report[f"loss_{t}"] = abs(losses[t].item() - float(z[f"loss_{t}"])) / abs(float(z[f"loss_{t}"]))
+    named = dict(model.named_parameters())
+    for name in G.SEMSEG_GRAD_NAMES:
+        report["grad_" + name] = rel_err(named[name].grad.cpu(), z["grad_" + name])
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in named.values() if p.grad is not None)).item()
+    report["grad_norm"] = abs(gn - float(z["grad_norm"])) / float(z["grad_norm"])
+    print(report)
+    bad = {k: v for k, v in report.items() if not v < BF16_TOL}
+    assert not bad, bad
+    assert all(p.grad is not None for p in named.values() if p.requires_grad)

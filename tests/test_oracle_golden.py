@@ -77,6 +77,28 @@ def test_tiny_end_to_end_fp32():
     assert all(g is not None for g in grads.values()), "every trainable tensor receives a gradient"
 
 
+def test_three_domain_semseg_end_to_end_fp32():
+    """rgb + depth + class map at stride 4: three-domain masking, stride-4 decoder output and masked CE are the
+    reference's; only the class-map input adapter (absent from the reference fork) is the fixture script's own."""
+    z = G.load("small_semseg_e2e.npz")
+    cfg = O.small_semseg_cfg()
+    sd = G.perturbed_state(cfg, seed=9)
+    x = G.seeded_inputs(cfg, B=2, seed=4)
+    noises = [torch.from_numpy(z[f"noise{i}"]) for i in range(3)]
+    losses, preds, masks, grads = O.step_grads(sd, cfg, x, torch.from_numpy(z["p"]), noises, torch.from_numpy(z["noise_all"]),
+                                               int(z["k"]))
+    for d in masks:
+        assert np.array_equal(masks[d].numpy(), z[f"mask_{d}"].astype(np.int64))
+    assert preds["semseg"].shape == (2, 9, 16, 16)
+    for t in preds:
+        assert rel_err(preds[t], z[f"pred_{t}"]) < FP32_TOL, t
+        assert abs(float(losses[t]) - float(z[f"loss_{t}"])) / abs(float(z[f"loss_{t}"])) < FP32_TOL, t
+    for name in G.SEMSEG_GRAD_NAMES:
+        assert rel_err(grads[name], z["grad_" + name]) < FP32_TOL, name
+    gn = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values() if g is not None))
+    assert abs(gn.item() - float(z["grad_norm"])) / float(z["grad_norm"]) < FP32_TOL
+
+
 def test_tiny_end_to_end_bf16_autocast():
     z, cfg, sd, x, p, noises, noise_all, k = _tiny_inputs()
     losses, preds, _ = O.step_losses(sd, cfg, x, p, noises, noise_all, k, autocast_dtype=torch.bfloat16)
