@@ -169,6 +169,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p, int nkp) 
 // backward, kernel 1: dQ per 32-query block.  K and V of the head live in LDS; Q, dO, O rows come straight from
 // global memory as fragments.  P is recomputed from the forward's log-sum-exp; delta = rowsum(dO * O) is computed from
 // the fragments and also written out for kernel 2.
+//
+// In exact arithmetic every row of dS sums to zero, so dQ = dS K = dS (K - 1 kbar^T) for any vector kbar.  In bf16 it
+// does not (delta comes from the rounded O, dS is rounded again for the MFMA), and the residual row sum times the
+// component all keys share lands in dQ: with near-uniform attention over similar keys that was a 15 % error.  The kernel
+// therefore accumulates rs = rowsum(bf16(dS)) and returns dS K - rs kbar^T with kbar = mean key, i.e. the product with
+// the centred keys, which brings dQ to the level of the other bf16 roundings (0.5 %).
 // --------------------------------------------------------------------------------------------
 template <int D, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs p, int nkp) {
@@ -176,12 +182,19 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs p, int nk
     constexpr int LDR = D + 8, KS = D / 16, DT = D / 32;
     bf16* Ks = (bf16*)smem;
     bf16* Vs = Ks + nkp * LDR;
+    float* kbar = (float*)(Vs + nkp * LDR);  // [D] mean key
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h2 = lane >> 5;
     const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
 
     stage_rows<D>(p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.kv_len, nkp, Ks, tid, NW * 64);
     stage_rows<D>(p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.kv_len, nkp, Vs, tid, NW * 64);
+    __syncthreads();
+    if (tid < D) {
+        float sum = 0.f;
+        for (int n = 0; n < p.kv_len; ++n) sum += (float)Ks[n * LDR + tid];
+        kbar[tid] = sum / (float)p.kv_len;
+    }
     __syncthreads();
 
     const float c = p.scale * LOG2E;
@@ -210,6 +223,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs p, int nk
         f32x16 dq[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
+        float rs = 0.f;  // this lane's share of rowsum(bf16(dS)) of query r
         for (int kt = 0; kt < nkt; ++kt) {
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
@@ -222,6 +236,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs p, int nk
             for (int i = 0; i < 16; ++i) {
                 const float pr = acc_row(i, h2) < lim ? __builtin_amdgcn_exp2f(s[i] * c - my_lse) : 0.f;
                 s[i] = pr * (dp[i] - my_delta) * p.scale;
+                rs += (float)(bf16)s[i];
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -231,6 +246,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs p, int nk
                     dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ks, LDR, kt * 32 + 16 * s2, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
             }
         }
+        rs += __shfl_xor(rs, 32, 64);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dq[dt][i] -= rs * kbar[dt * 32 + acc_row(i, h2)];
         if (qvalid) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
@@ -365,7 +385,7 @@ template <int D, int NW>
 static int launch_dq(const AttnArgs& a, hipStream_t s) {
     static bool reserved = false;
     const int nkp = pad32(a.kv_len);
-    return launch_with_lds(attn_bwd_dq_kernel<D, NW>, "attn_bwd_dq", sizeof(bf16) * 2 * (size_t)nkp * (D + 8), a.B * a.H, NW * 64, s, a, nkp, reserved);
+    return launch_with_lds(attn_bwd_dq_kernel<D, NW>, "attn_bwd_dq", sizeof(bf16) * 2 * (size_t)nkp * (D + 8) + sizeof(float) * D, a.B * a.H, NW * 64, s, a, nkp, reserved);
 }
 template <int D, int NW>
 static int launch_dkv(const AttnArgs& a, hipStream_t s) {

@@ -275,3 +275,44 @@ def test_three_domain_semseg_model_vs_reference_golden():
     bad = {k: v for k, v in report.items() if not v < BF16_TOL}
     assert not bad, bad
     assert all(p.grad is not None for p in named.values() if p.requires_grad)
+
+
+def test_vit_b_rgb_depth_semseg_step_vs_oracle():
+    """ViT-B/16 with rgb + depth + 133-class map at stride 4 (588 tokens, 98 visible), decoders rgb / depth / semseg /
+    norm_rgb, semseg logits in fp32, batch 4: HIP step vs the fp32 oracle, every parameter gradient, reproducibility."""
+    import multimae_amd as M
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    cfg = O.vit_b_rgbd_semseg_cfg(extra_norm_pix=True)
+    sd = G.perturbed_state(cfg, seed=21)
+    B, k = 4, 98
+    x = G.seeded_inputs(cfg, B=B, seed=22)
+    p, noises, noise_all = O.draw_mask_randomness(B, [196] * 3, 1.0, torch.Generator().manual_seed(23))
+    o_losses, o_preds, o_masks, o_grads = O.step_grads(sd, cfg, x, p, noises, noise_all, k)
+    model = _build_semseg(cfg)
+    model.load_state_dict(sd, strict=True)
+    model.cuda()
+    fns = {"rgb": (M.MaskedMSELoss(16, 1), "rgb"), "depth": (M.MaskedL1Loss(16, 1), "depth"),
+           "semseg": (M.MaskedCrossEntropyLoss(16, 4), "semseg"), "norm_rgb": (M.MaskedMSELoss(16, 1, norm_pix=True), "rgb")}
+    xg = {d: t.cuda() for d, t in x.items()}
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        preds, masks = model(xg, num_encoded_tokens=k, alphas=1.0, mask_randomness=(p, noises, noise_all),
+                             fp32_output_adapters=["semseg"])
+        losses = {t: fn(preds[t], xg[tg], mask=masks[tg]) for t, (fn, tg) in fns.items()}
+        sum(losses.values()).backward()
+        return preds, masks, losses, {n: q.grad for n, q in model.named_parameters() if q.requires_grad}
+    preds, masks, losses, grads = step()
+    for d in masks:
+        assert torch.equal(masks[d].cpu(), o_masks[d]), d
+    assert preds["semseg"].shape == (B, 133, 56, 56) and preds["semseg"].dtype == torch.float32
+    errs = {f"pred_{t}": rel_err(preds[t].float().cpu(), o_preds[t]) for t in preds}
+    errs.update({f"loss_{t}": abs(losses[t].item() - float(o_losses[t])) / abs(float(o_losses[t])) for t in losses})
+    gerr = {n: rel_err(g.cpu(), o_grads[n]) for n, g in grads.items()}
+    print({k_: f"{v:.2e}" for k_, v in errs.items()}, "worst grads:", sorted(((e, n) for n, e in gerr.items()), reverse=True)[:4])
+    assert set(grads) == set(o_grads)
+    assert all(v < BF16_TOL for v in errs.values()), errs
+    assert all(e < BF16_TOL for e in gerr.values()), {n: e for n, e in gerr.items() if e >= BF16_TOL}
+    preds2, _, _, grads2 = step()
+    assert all(torch.equal(preds[t], preds2[t]) for t in preds) and all(torch.equal(grads[n], grads2[n]) for n in grads)
