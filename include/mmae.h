@@ -190,11 +190,16 @@ int mmae_masked_ce(const void* logits, int logits_is_bf16, const int64_t* target
 
 /* ---- optimiser step over flat buffers (AdamW; run_pretraining_multimae_v2.py:339-344) -----------
  * p, g, m, v are f32 [n]; elements [0, n_decay) use weight_decay, the rest none.
- * grad_scale multiplies g first (1/world_size for the data-parallel mean, clip factor).
- * If w_bf16 != NULL the updated parameters are also written there as bf16. */
+ * grad_scale multiplies g first (1/world_size for the data-parallel mean).
+ * If w_bf16 != NULL the updated parameters are also written there as bf16.
+ * Gradient clipping / skipping of NativeScalerWithGradNormCount (utils/native_scaler.py:33-51) without a host round trip:
+ * grad_sumsq (device, from mmae_sumsq over g; NULL = neither) gives norm = sqrt(sumsq) * grad_scale; max_norm > 0 scales
+ * the gradient by min(1, max_norm / (norm + 1e-6)); skip_norm > 0 leaves p, m, v untouched when norm >= skip_norm.
+ * step_dev (device int, optional): number of updates applied so far; when given, the bias corrections use
+ * step_dev[0] + 1 instead of `step`, and the count advances only if the update was applied. */
 int mmae_adamw_flat(float* p, const float* g, float* m, float* v, long n, long n_decay, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, float grad_scale, void* w_bf16,
-                    mmae_stream_t stream);
+                    const float* grad_sumsq, float max_norm, float skip_norm, int* step_dev, mmae_stream_t stream);
 /* sum of squares of f32 [n] into out[0] (f32); partials in workspace (>= 4096 bytes) */
 int mmae_sumsq(const float* x, long n, float* out, void* workspace, size_t workspace_bytes, mmae_stream_t stream);
 /* dst(bf16)[rows, cols] = src(f32)[rows, cols]; dst_t(bf16)[cols, rows] = transpose (either may be NULL) */

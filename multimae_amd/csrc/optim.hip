@@ -2,19 +2,46 @@
 // HBM-bound: AdamW moves 28 bytes per parameter (p, g, m, v read; p, m, v written) (+2 for the bf16 copy).
 #include "common.h"
 
-__global__ void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                  float* __restrict__ v, long n4, long n_decay, float lr, float b1, float b2, float eps,
-                                  float wd, float bc1, float bc2_sqrt, float gscale, bf16* __restrict__ wb) {
+// Clipping / skipping without a host round trip: `sumsq` (device) holds sum(g^2) of the raw gradient buffer, the true gradient
+// is g * gscale.  max_norm > 0 scales by min(1, max_norm / (norm + 1e-6)) (torch.nn.utils.clip_grad_norm_); skip_norm > 0
+// leaves every buffer untouched when norm >= skip_norm.  `step_dev` (device, optional) is the count of updates applied so far:
+// the bias corrections then use step_dev[0] + 1 and a skipped update does not advance it.
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v; long n4, n_decay;
+    float lr, b1, b2, eps, wd, gscale;
+    int step_host;
+    const float* sumsq; float max_norm, skip_norm;
+    int* step_dev;
+    bf16* wb;
+};
+
+__device__ __forceinline__ bool adam_plan(const AdamArgs& a, float& gs, int& step) {
+    gs = a.gscale;
+    step = a.step_dev ? a.step_dev[0] + 1 : a.step_host;
+    if (a.sumsq) {
+        const float nrm = sqrtf(a.sumsq[0]) * a.gscale;
+        if (a.skip_norm > 0.f && nrm >= a.skip_norm) return false;
+        if (a.max_norm > 0.f) gs *= fminf(1.0f, a.max_norm / (nrm + 1e-6f));
+    }
+    return true;
+}
+
+__global__ void adamw_flat_kernel(AdamArgs a) {
     // PyTorch AdamW: p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
     //                p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
-    const float step = lr / bc1;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float gscale; int t;
+    if (!adam_plan(a, gscale, t)) return;
+    const float bc1 = 1.0f - powf(a.b1, (float)t);
+    const float bc2_sqrt = sqrtf(1.0f - powf(a.b2, (float)t));
+    const float step = a.lr / bc1, lr = a.lr, wd = a.wd, b1 = a.b1, b2 = a.b2, eps = a.eps;
+    float* p = a.p; float* m = a.m; float* v = a.v; const float* g = a.g; bf16* wb = a.wb;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n4; i += (long)gridDim.x * blockDim.x) {
         f32x4 pp = ((f32x4*)p)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
         const f32x4 gg = ((const f32x4*)g)[i] * gscale;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float x = pp[e];
-            if (i * 4 + e < n_decay) x *= 1.0f - lr * wd;
+            if (i * 4 + e < a.n_decay) x *= 1.0f - lr * wd;
             const float m1 = b1 * mm[e] + (1.0f - b1) * gg[e];
             const float v1 = b2 * vv[e] + (1.0f - b2) * gg[e] * gg[e];
             x -= step * m1 / (sqrtf(v1) / bc2_sqrt + eps);
@@ -27,21 +54,29 @@ __global__ void adamw_flat_kernel(float* __restrict__ p, const float* __restrict
         }
     }
 }
+// runs after the update kernel on the same stream: advance the device step count unless the update was skipped
+__global__ void adamw_advance_kernel(AdamArgs a) {
+    float gs; int t;
+    if (threadIdx.x == 0 && blockIdx.x == 0 && adam_plan(a, gs, t)) a.step_dev[0] = t;
+}
 
 extern "C" int mmae_adamw_flat(float* p, const float* g, float* m, float* v, long n, long n_decay, float lr, float beta1,
                                float beta2, float eps, float weight_decay, int step, float grad_scale, void* w_bf16,
-                               hipStream_t stream) {
+                               const float* grad_sumsq, float max_norm, float skip_norm, int* step_dev, hipStream_t stream) {
     MMAE_REQUIRE(p && g && m && v, MMAE_EINVAL, "adamw_flat: null pointer");
     MMAE_REQUIRE(n >= 0 && n % 4 == 0 && n_decay >= 0 && n_decay <= n, MMAE_ESHAPE, "adamw_flat: n=%ld must be a multiple of 4, n_decay=%ld within it", n, n_decay);
-    MMAE_REQUIRE(step >= 1, MMAE_EINVAL, "adamw_flat: step counts from 1");
+    MMAE_REQUIRE(step_dev || step >= 1, MMAE_EINVAL, "adamw_flat: step counts from 1");
+    MMAE_REQUIRE(grad_sumsq || (max_norm <= 0.f && skip_norm <= 0.f), MMAE_EINVAL, "adamw_flat: clipping / skipping needs the gradient sum of squares");
     if (n == 0) return MMAE_OK;
-    const float bc1 = 1.0f - powf(beta1, (float)step);
-    const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
-    const long n4 = n / 4;
-    int blocks = (int)((n4 + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(adamw_flat_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n4, n_decay, lr, beta1, beta2, eps,
-                       weight_decay, bc1, bc2s, grad_scale, (bf16*)w_bf16);
+    AdamArgs a = {p, g, m, v, n / 4, n_decay, lr, beta1, beta2, eps, weight_decay, grad_scale, step, grad_sumsq, max_norm, skip_norm,
+                  step_dev, (bf16*)w_bf16};
+    int blocks = (int)((a.n4 + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adamw_flat_kernel, dim3(blocks), dim3(256), 0, stream, a);
     MMAE_CHECK_LAUNCH("adamw_flat");
+    if (step_dev) {
+        hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(64), 0, stream, a);
+        MMAE_CHECK_LAUNCH("adamw_advance");
+    }
     return MMAE_OK;
 }
 

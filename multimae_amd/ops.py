@@ -422,11 +422,17 @@ def masked_ce(logits: torch.Tensor, target: torch.Tensor, mask: Optional[torch.T
 
 
 # --------------------------------------------------------------------------------------------- optimiser
-def adamw_flat(p, g, m, v, n_decay, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, w_bf16=None):
+def adamw_flat(p, g, m, v, n_decay, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, w_bf16=None, grad_sumsq=None,
+               max_norm=0.0, skip_norm=0.0, step_dev=None):
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _req(t, F32, f"adamw {n}")
+    if grad_sumsq is not None:
+        _req(grad_sumsq, F32, "adamw grad_sumsq")
+    if step_dev is not None:
+        _req(step_dev, torch.int32, "adamw step_dev")
     _lib.check(_L().mmae_adamw_flat(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(n_decay), lr, beta1, beta2, eps,
-                                    weight_decay, int(step), float(grad_scale), _ptr(w_bf16), _stream()), "adamw_flat")
+                                    weight_decay, int(step), float(grad_scale), _ptr(w_bf16), _ptr(grad_sumsq), float(max_norm or 0.0),
+                                    float(skip_norm or 0.0), _ptr(step_dev), _stream()), "adamw_flat")
 
 
 def sumsq(x: torch.Tensor, out: Optional[torch.Tensor] = None):

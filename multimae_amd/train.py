@@ -175,55 +175,98 @@ class GradBuckets:
 
 class FlatAdamW:
     """AdamW over FlatParams in one kernel launch (PyTorch AdamW semantics; betas / weight decay as the reference's
-    pretraining defaults, pretrain_argparser.py:44-64 there)."""
+    pretraining defaults, pretrain_argparser.py:44-64 there), with the gradient clipping / skipping of the reference's
+    NativeScalerWithGradNormCount (utils/native_scaler.py:33-51) decided on the device."""
 
     def __init__(self, flat: FlatParams, lr=1e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05):
         self.flat = flat
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.exp_avg = torch.zeros_like(flat.params)
         self.exp_avg_sq = torch.zeros_like(flat.params)
-        self.step_count = 0
+        self.step_count = 0   # calls of step()
+        self.step_dev = None  # applied updates (device int32), created on the first step that may skip
 
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: float = 1.0, clip_grad: Optional[float] = None, skip_grad: Optional[float] = None,
+             grad_sumsq: Optional[torch.Tensor] = None):
+        """grad_sumsq: device scalar sum(g^2) of the raw gradient buffer (computed here if clipping / skipping needs it).
+        With skip_grad the number of applied updates lives on the device (no host synchronisation)."""
         self.step_count += 1
+        if (clip_grad or skip_grad) and grad_sumsq is None:
+            grad_sumsq = self.grad_norm_sq()
+        if skip_grad and self.step_dev is None:
+            self.step_dev = torch.full((1,), self.step_count - 1, dtype=torch.int32, device=self.flat.params.device)
         ops.adamw_flat(self.flat.params, self.flat.grads, self.exp_avg, self.exp_avg_sq, self.flat.n_decay, self.lr,
                        self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale,
-                       w_bf16=self.flat.w_bf16)
+                       w_bf16=self.flat.w_bf16, grad_sumsq=grad_sumsq if (clip_grad or skip_grad) else None,
+                       max_norm=clip_grad or 0.0, skip_norm=skip_grad or 0.0, step_dev=self.step_dev)
         self.flat.refresh_transposes()
         Fn.bump_weight_epoch()
 
-    def grad_norm_sq(self):
+    def grad_norm_sq(self) -> torch.Tensor:
         return ops.sumsq(self.flat.grads)
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr,
+        applied = int(self.step_dev.item()) if self.step_dev is not None else self.step_count
+        return {"step": applied, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr,
                 "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}
 
     def load_state_dict(self, sd):
         self.step_count = int(sd["step"])
+        self.step_dev = None
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+def cosine_scheduler(base_value: float, final_value: float, epochs: int, niter_per_ep: int, warmup_epochs=0,
+                     start_warmup_value=0, warmup_steps=-1):
+    """Per-iteration values: linear warm-up then half-cosine decay (reference: utils/native_scaler.py:86-117, same
+    arithmetic: the warm-up ramp exists only when warmup_epochs > 0, its length is warmup_steps when that is > 0)."""
+    import math
+    import numpy as np
+    warmup_iters = warmup_epochs * niter_per_ep
+    if warmup_steps > 0:
+        warmup_iters = warmup_steps
+    warmup = np.linspace(start_warmup_value, base_value, warmup_iters) if warmup_epochs > 0 else np.array([])
+    n = epochs * niter_per_ep - warmup_iters
+    sched = np.array([final_value + 0.5 * (base_value - final_value) * (1 + math.cos(math.pi * i / n)) for i in range(n)])
+    sched = np.concatenate((warmup, sched))
+    assert len(sched) == epochs * niter_per_ep
+    return sched
 
 
 class PretrainStep:
     """model + losses + flat AdamW + gradient buckets: one call = one optimisation step on a batch already on the device."""
 
     def __init__(self, model, losses, num_encoded_tokens=98, alphas=1.0, lr=1e-4, weight_decay=0.05, betas=(0.9, 0.95),
-                 bucket_mb=64.0):
+                 bucket_mb=64.0, clip_grad=None, skip_grad=None, lr_schedule_values=None, wd_schedule_values=None,
+                 start_step=0, sample_tasks_uniformly=False, fp32_output_adapters=()):
+        """clip_grad / skip_grad: max_norm / max_skip_norm of the reference's train_one_epoch
+        (run_pretraining_multimae.py:512-519).  lr_schedule_values / wd_schedule_values: per-iteration arrays
+        (cosine_scheduler) applied before each step as at :424-436; iteration = start_step + calls so far."""
         self.model, self.losses = model, losses
         self.k, self.alphas = num_encoded_tokens, alphas
+        self.clip_grad, self.skip_grad = clip_grad, skip_grad
+        self.lr_values, self.wd_values, self.it = lr_schedule_values, wd_schedule_values, start_step
+        self.uniform, self.fp32_out = sample_tasks_uniformly, list(fp32_output_adapters)
         self.flat = FlatParams(model)
         self.buckets = GradBuckets(self.flat, bucket_mb=bucket_mb)
         self.opt = FlatAdamW(self.flat, lr=lr, betas=betas, weight_decay=weight_decay)
         self.world = self.buckets.world
 
     def __call__(self, batch, mask_randomness=None):
+        if self.lr_values is not None:
+            self.opt.lr = float(self.lr_values[self.it])
+        if self.wd_values is not None and self.opt.weight_decay > 0:
+            self.opt.weight_decay = float(self.wd_values[self.it])
+        self.it += 1
         self.flat.zero_grad()
-        preds, masks = self.model(batch, num_encoded_tokens=self.k, alphas=self.alphas, mask_randomness=mask_randomness)
+        inputs = {d: t for d, t in batch.items() if d in self.model.input_adapters}
+        preds, masks = self.model(inputs, num_encoded_tokens=self.k, alphas=self.alphas, mask_randomness=mask_randomness,
+                                  sample_tasks_uniformly=self.uniform, fp32_output_adapters=self.fp32_out)
         task_losses = {t: fn(preds[t], batch[tgt], mask=masks.get(tgt)) for t, (fn, tgt) in self.losses.items()}
         loss = sum(task_losses.values())
         loss.backward()
         self.buckets.finish()
-        gn2 = self.opt.grad_norm_sq()
-        self.opt.step(grad_scale=1.0 / self.world)
+        gn2 = self.opt.grad_norm_sq()  # of the summed (not yet averaged) gradients: norm = sqrt(gn2) / world
+        self.opt.step(grad_scale=1.0 / self.world, clip_grad=self.clip_grad, skip_grad=self.skip_grad, grad_sumsq=gn2)
         return loss.detach(), task_losses, gn2

@@ -5,6 +5,12 @@ import torch
 
 from oracle import multimae_oracle as O
 
+SCHEDULE_CASES = [
+    dict(base_value=1e-4, final_value=0.0, epochs=20, niter_per_ep=30, warmup_epochs=2, warmup_steps=-1),
+    dict(base_value=2.5e-3, final_value=1e-6, epochs=7, niter_per_ep=13, warmup_epochs=1, start_warmup_value=1e-6, warmup_steps=5),
+    dict(base_value=0.05, final_value=0.05, epochs=3, niter_per_ep=11),
+]
+
 SEMSEG_GRAD_NAMES = [
     "global_tokens",
     "input_adapters.semseg.class_emb.weight",

@@ -253,6 +253,18 @@ def gen_semseg_e2e(fname="small_semseg_e2e.npz"):
     print(fname, "ok; losses", {t: float(v) for t, v in losses.items()})
 
 
+def gen_schedule():
+    import contextlib
+    import io
+    from utils.native_scaler import cosine_scheduler
+    out = {}
+    for i, kw in enumerate(G.SCHEDULE_CASES):
+        with contextlib.redirect_stdout(io.StringIO()):
+            out[f"case{i}"] = cosine_scheduler(**kw)
+    np.savez_compressed(os.path.join(HERE, "schedule.npz"), **out)
+    print("schedule ok")
+
+
 def gen_losses():
     out = {}
     g = torch.Generator().manual_seed(21)
@@ -348,6 +360,7 @@ if __name__ == "__main__":
             globals()[fn]()
         sys.exit(0)
     gen_semseg_e2e()
+    gen_schedule()
     gen_masks()
     gen_posemb()
     gen_tiny_e2e()

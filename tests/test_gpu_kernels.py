@@ -443,3 +443,34 @@ def test_unpatchify_patch4_and_fp32_output(ops):
     back = (x.float() @ w.float().t() + bias)
     assert torch.equal(rows, back.bfloat16()) or rel_err(rows.float().cpu(), back.cpu()) < 4e-3
     assert torch.equal(ops.patchify_bf16(img16, P), rows)
+
+
+def test_adamw_clip_and_skip_on_device(ops):
+    """Clipping = torch.nn.utils.clip_grad_norm_ followed by AdamW; a skipped update changes nothing and does not advance
+    the bias-correction step (the reference skips optimizer.step(), utils/native_scaler.py:41-46)."""
+    n, n_decay = 40_000, 24_000
+    g0 = torch.Generator().manual_seed(8)
+    p = torch.randn(n, generator=g0).cuda()
+    ref = [p[:n_decay].clone().requires_grad_(True), p[n_decay:].clone().requires_grad_(True)]
+    opt = torch.optim.AdamW([{"params": [ref[0]], "weight_decay": 0.05}, {"params": [ref[1]], "weight_decay": 0.0}],
+                            lr=1e-3, betas=(0.9, 0.95), eps=1e-8)
+    m = torch.zeros_like(p); v = torch.zeros_like(p)
+    step_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+    scales = [1.0, 30.0, 0.01, 5.0]     # gradient magnitudes: the second one trips the skip threshold
+    world_scale = 0.5
+    for it, sc in enumerate(scales):
+        grad = torch.randn(n, generator=g0).cuda() * sc
+        true = grad * world_scale
+        norm = true.norm().item()
+        before = p.clone()
+        ops.adamw_flat(p, grad, m, v, n_decay, 1e-3, 0.9, 0.95, 1e-8, 0.05, it + 1, grad_scale=world_scale,
+                       grad_sumsq=ops.sumsq(grad), max_norm=150.0, skip_norm=2000.0, step_dev=step_dev)
+        if norm >= 2000.0:
+            assert torch.equal(p, before)
+            continue
+        ref[0].grad = true[:n_decay].clone(); ref[1].grad = true[n_decay:].clone()
+        total = torch.nn.utils.clip_grad_norm_(ref, 150.0)
+        assert abs(total.item() - norm) / norm < 1e-5
+        opt.step()
+    assert step_dev.item() == 3
+    assert rel_err(p[:n_decay], ref[0].detach()) < 1e-5 and rel_err(p[n_decay:], ref[1].detach()) < 1e-5

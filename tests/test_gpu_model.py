@@ -316,3 +316,37 @@ def test_vit_b_rgb_depth_semseg_step_vs_oracle():
     assert all(e < BF16_TOL for e in gerr.values()), {n: e for n, e in gerr.items() if e >= BF16_TOL}
     preds2, _, _, grads2 = step()
     assert all(torch.equal(preds[t], preds2[t]) for t in preds) and all(torch.equal(grads[n], grads2[n]) for n in grads)
+
+
+def test_pretrain_step_applies_schedules_and_clipping():
+    """PretrainStep with per-iteration lr / weight-decay arrays and gradient clipping equals autograd delivery +
+    clip_grad_norm_ + torch AdamW with the same per-step values."""
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    from multimae_amd.train import PretrainStep, cosine_scheduler, split_decay
+    cfg = O.small_cfg()
+    sd = G.perturbed_state(cfg, seed=7)
+    x = {d: t.cuda() for d, t in G.seeded_inputs(cfg, B=4, seed=3).items()}
+    rnd = O.draw_mask_randomness(4, [16, 16], 1.0, torch.Generator().manual_seed(2))
+    lrs = cosine_scheduler(1e-3, 1e-5, 1, 4, warmup_epochs=1, warmup_steps=2)
+    wds = cosine_scheduler(0.05, 0.1, 1, 4)
+    clip = 0.5
+
+    ref = _build(cfg); ref.load_state_dict(sd); ref.cuda()
+    decay, no_decay = split_decay(ref)
+    opt = torch.optim.AdamW([{"params": [p for _, p in decay], "weight_decay": 0.05},
+                             {"params": [p for _, p in no_decay], "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.95))
+    model = _build(cfg); model.load_state_dict(sd); model.cuda()
+    step = PretrainStep(model, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05, clip_grad=clip,
+                        lr_schedule_values=lrs, wd_schedule_values=wds)
+    for it in range(3):
+        opt.param_groups[0]["lr"] = opt.param_groups[1]["lr"] = float(lrs[it])
+        opt.param_groups[0]["weight_decay"] = float(wds[it])
+        _hip_step(ref, cfg, {d: t.cpu() for d, t in x.items()}, rnd, 8)
+        total = torch.nn.utils.clip_grad_norm_([p for p in ref.parameters() if p.requires_grad], clip)
+        opt.step()
+        loss, _, gn2 = step(x, mask_randomness=rnd)
+        assert abs(gn2.sqrt().item() - total.item()) / total.item() < 1e-4 and total.item() > clip  # clipping is active
+    named = dict(ref.named_parameters())
+    worst = max(rel_err(p.detach(), named[n].detach()) for n, p in model.named_parameters() if p.requires_grad)
+    assert worst < 2e-5, worst

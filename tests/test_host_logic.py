@@ -24,8 +24,21 @@ def test_library_exports_every_declared_symbol():
     # argument validation happens before any launch: a bad call returns a code and a message, no GPU needed
     rc = lib.mmae_gemm_nt(0, None, 0, None, 0, 1, 1, 1, None, None, 0, None, None, 0, None)
     assert rc == -1 and b"null" in lib.mmae_last_error()
-    rc = lib.mmae_adamw_flat(1, 1, 1, 1, 6, 0, 0.1, 0.9, 0.95, 1e-8, 0.0, 1, 1.0, None, None)
+    rc = lib.mmae_adamw_flat(1, 1, 1, 1, 6, 0, 0.1, 0.9, 0.95, 1e-8, 0.0, 1, 1.0, None, None, 0.0, 0.0, None, None)
     assert rc == -2 and b"multiple of 4" in lib.mmae_last_error()
+    rc = lib.mmae_adamw_flat(1, 1, 1, 1, 8, 0, 0.1, 0.9, 0.95, 1e-8, 0.0, 1, 1.0, None, None, 1.0, 0.0, None, None)
+    assert rc == -1 and b"sum of squares" in lib.mmae_last_error()
+
+
+def test_cosine_scheduler_matches_reference_values():
+    """Fixture: values of the reference's utils.native_scaler.cosine_scheduler for three argument sets."""
+    import numpy as np
+    from multimae_amd.train import cosine_scheduler
+    from tests.golden import common as G
+    z = G.load("schedule.npz")
+    for i, kw in enumerate(G.SCHEDULE_CASES):
+        got = cosine_scheduler(**kw)
+        assert got.shape == z[f"case{i}"].shape and np.array_equal(got, z[f"case{i}"]), kw
 
 
 def test_state_dict_layout_matches_reference_names():
