@@ -188,6 +188,13 @@ int mmae_masked_ce(const void* logits, int logits_is_bf16, const int64_t* target
                    int W, int patch, float label_smoothing, float* loss, void* d_logits, void* workspace,
                    size_t workspace_bytes, mmae_stream_t stream);
 
+/* Truncated depth standardisation (run_pretraining_multimae.py:448-459): per sample (B rows of n values),
+ * out = (x - mean) / sqrt(var + eps) with mean / unbiased var over the sorted values of ranks
+ * [int(lo_frac * n), int(hi_frac * n)) (0.1, 0.9, eps 1e-6 in the reference).  Order statistics by radix select; no sort.
+ * out may alias depth. */
+int mmae_standardize_depth(const float* depth, float* out, int B, long n, double lo_frac, double hi_frac, float eps,
+                           mmae_stream_t stream);
+
 /* ---- optimiser step over flat buffers (AdamW; run_pretraining_multimae_v2.py:339-344) -----------
  * p, g, m, v are f32 [n]; elements [0, n_decay) use weight_decay, the rest none.
  * grad_scale multiplies g first (1/world_size for the data-parallel mean).

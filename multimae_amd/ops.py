@@ -421,6 +421,18 @@ def masked_ce(logits: torch.Tensor, target: torch.Tensor, mask: Optional[torch.T
     return loss, d_logits
 
 
+def standardize_depth(depth: torch.Tensor, lo_frac: float = 0.1, hi_frac: float = 0.9, eps: float = 1e-6,
+                      out: Optional[torch.Tensor] = None):
+    """Per sample: (x - mean) / sqrt(var + eps) with the moments of the sorted values of ranks [int(lo*n), int(hi*n))."""
+    _req(depth, F32, "standardize_depth depth")
+    B = depth.shape[0]
+    out = torch.empty_like(depth) if out is None else _req(out, F32, "standardize_depth out")
+    if B:
+        _lib.check(_L().mmae_standardize_depth(_ptr(depth), _ptr(out), B, depth.numel() // B, lo_frac, hi_frac, eps, _stream()),
+                   "standardize_depth")
+    return out
+
+
 # --------------------------------------------------------------------------------------------- optimiser
 def adamw_flat(p, g, m, v, n_decay, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, w_bf16=None, grad_sumsq=None,
                max_norm=0.0, skip_norm=0.0, step_dev=None):

@@ -239,7 +239,7 @@ class PretrainStep:
 
     def __init__(self, model, losses, num_encoded_tokens=98, alphas=1.0, lr=1e-4, weight_decay=0.05, betas=(0.9, 0.95),
                  bucket_mb=64.0, clip_grad=None, skip_grad=None, lr_schedule_values=None, wd_schedule_values=None,
-                 start_step=0, sample_tasks_uniformly=False, fp32_output_adapters=()):
+                 start_step=0, sample_tasks_uniformly=False, fp32_output_adapters=(), standardize_depth=False):
         """clip_grad / skip_grad: max_norm / max_skip_norm of the reference's train_one_epoch
         (run_pretraining_multimae.py:512-519).  lr_schedule_values / wd_schedule_values: per-iteration arrays
         (cosine_scheduler) applied before each step as at :424-436; iteration = start_step + calls so far."""
@@ -248,6 +248,7 @@ class PretrainStep:
         self.clip_grad, self.skip_grad = clip_grad, skip_grad
         self.lr_values, self.wd_values, self.it = lr_schedule_values, wd_schedule_values, start_step
         self.uniform, self.fp32_out = sample_tasks_uniformly, list(fp32_output_adapters)
+        self.standardize_depth = standardize_depth  # truncated standardisation of batch["depth"] (reference :448-459)
         self.flat = FlatParams(model)
         self.buckets = GradBuckets(self.flat, bucket_mb=bucket_mb)
         self.opt = FlatAdamW(self.flat, lr=lr, betas=betas, weight_decay=weight_decay)
@@ -260,6 +261,9 @@ class PretrainStep:
             self.opt.weight_decay = float(self.wd_values[self.it])
         self.it += 1
         self.flat.zero_grad()
+        if self.standardize_depth and "depth" in batch:
+            batch = dict(batch)
+            batch["depth"] = ops.standardize_depth(batch["depth"].contiguous())
         inputs = {d: t for d, t in batch.items() if d in self.model.input_adapters}
         preds, masks = self.model(inputs, num_encoded_tokens=self.k, alphas=self.alphas, mask_randomness=mask_randomness,
                                   sample_tasks_uniformly=self.uniform, fp32_output_adapters=self.fp32_out)

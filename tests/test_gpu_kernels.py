@@ -474,3 +474,24 @@ def test_adamw_clip_and_skip_on_device(ops):
         opt.step()
     assert step_dev.item() == 3
     assert rel_err(p[:n_decay], ref[0].detach()) < 1e-5 and rel_err(p[n_decay:], ref[1].detach()) < 1e-5
+
+
+def test_truncated_depth_standardisation(ops):
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    z = G.load("depth_std.npz")
+    got = ops.standardize_depth(torch.from_numpy(z["depth"]).cuda())
+    assert rel_err(got.cpu(), z["out"]) < FP32_TOL
+    g = torch.Generator().manual_seed(17)
+    d = torch.rand(6, 1, 224, 224, generator=g) * 9.0
+    d[1] = torch.round(d[1])                 # heavy ties, also across the two cut ranks
+    d[2] = -d[2]                             # negative values
+    d[3, 0, :120] = 2.5                      # more than half the map is one value: both cuts land on it
+    d[4] = torch.randn(1, 224, 224, generator=g) * 1e-3   # mixed signs, small scale
+    ref = O.standardize_depth(d)
+    got = ops.standardize_depth(d.cuda())
+    for b in range(d.shape[0]):
+        assert rel_err(got[b].cpu(), ref[b]) < FP32_TOL, b
+    x = d.cuda().clone()
+    ops.standardize_depth(x, out=x)          # in place
+    assert torch.equal(x, got)
