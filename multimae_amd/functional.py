@@ -192,6 +192,105 @@ class BlockFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------
+# the same pieces as stand-alone modules (no LayerNorm / residual around them): Mlp, Attention, CrossAttention
+# called directly, as the reference's classes can be (multimae/multimae_utils.py:162-169, :191-207, :224-247)
+# ---------------------------------------------------------------------------------------------
+class MlpFn(torch.autograd.Function):
+    """fc2(gelu(fc1(x))), x f32 [..., D] -> f32 [..., D_out]."""
+
+    @staticmethod
+    def forward(ctx, x, fc1_w, fc1_b, fc2_w, fc2_b):
+        xb = ops.cast_bf16(x.contiguous().reshape(-1, x.shape[-1]))
+        w1, w1t = bf16_weights(fc1_w)
+        w2, w2t = bf16_weights(fc2_w)
+        h, act = ops.gemm_nt(ops.EPI_GELU, xb, w1, fc1_b)
+        y = ops.gemm_nt(ops.EPI_F32, act, w2, fc2_b)
+        ctx.saved = (xb, h, act, w1t, w2t, (fc1_w, fc1_b, fc2_w, fc2_b), x.shape)
+        return y.reshape(*x.shape[:-1], fc2_w.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        xb, h, act, w1t, w2t, (fc1_w, fc1_b, fc2_w, fc2_b), shape = ctx.saved
+        ctx.saved = None
+        gb = _bf16(g.contiguous().reshape(-1, g.shape[-1]))
+        dh = ops.gemm_nt(ops.EPI_DGELU, gb, w2t, None, aux=h)
+        dw2, db2 = _lin_grads(gb, act, fc2_w, fc2_b)
+        dx = ops.gemm_nt(ops.EPI_F32, dh, w1t, None)
+        dw1, db1 = _lin_grads(dh, xb, fc1_w, fc1_b)
+        return dx.reshape(shape), dw1, db1, dw2, db2
+
+
+class AttentionFn(torch.autograd.Function):
+    """proj(softmax(q k^T scale) v) with q, k, v = split(qkv(x)), x f32 [B,N,D]."""
+
+    @staticmethod
+    def forward(ctx, x, heads, qkv_w, qkv_b, proj_w, proj_b):
+        B, N, D = x.shape
+        d = D // heads
+        xb = ops.cast_bf16(x.contiguous().reshape(B * N, D))
+        wq, wqt = bf16_weights(qkv_w)
+        wp, wpt = bf16_weights(proj_w)
+        qkv = ops.gemm_nt(ops.EPI_BF16, xb, wq, qkv_b)
+        o, lse = ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, heads, N, N, d, d ** -0.5)
+        y = ops.gemm_nt(ops.EPI_F32, o, wp, proj_b)
+        ctx.saved = (xb, qkv, o, lse, wqt, wpt, (qkv_w, qkv_b, proj_w, proj_b), (B, N, D, heads))
+        return y.reshape(B, N, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        xb, qkv, o, lse, wqt, wpt, (qkv_w, qkv_b, proj_w, proj_b), (B, N, D, heads) = ctx.saved
+        ctx.saved = None
+        d = D // heads
+        gb = _bf16(g.contiguous().reshape(B * N, D))
+        d_o = ops.gemm_nt(ops.EPI_BF16, gb, wpt, None)
+        dwp, dbp = _lin_grads(gb, o, proj_w, proj_b)
+        dqkv = torch.empty_like(qkv)
+        ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, d_o, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                     B, heads, N, N, d, d ** -0.5)
+        dx = ops.gemm_nt(ops.EPI_F32, dqkv, wqt, None)
+        dwq, dbq = _lin_grads(dqkv, xb, qkv_w, qkv_b)
+        return dx.reshape(B, N, D), None, dwq, dbq, dwp, dbp
+
+
+class CrossAttentionFn(torch.autograd.Function):
+    """proj(softmax(q(x) k(ctx)^T scale) v(ctx)), x f32 [B,N,D], context f32 [B,M,D]."""
+
+    @staticmethod
+    def forward(ctx, x, context, heads, q_w, q_b, kv_w, kv_b, proj_w, proj_b):
+        B, N, D = x.shape
+        M = context.shape[1]
+        d = D // heads
+        xb = ops.cast_bf16(x.contiguous().reshape(B * N, D))
+        cb = ops.cast_bf16(context.contiguous().reshape(B * M, D))
+        wq, wqt = bf16_weights(q_w)
+        wkv, wkvt = bf16_weights(kv_w)
+        wp, wpt = bf16_weights(proj_w)
+        q = ops.gemm_nt(ops.EPI_BF16, xb, wq, q_b)
+        kv = ops.gemm_nt(ops.EPI_BF16, cb, wkv, kv_b)
+        o, lse = ops.attn_fwd(q, kv[:, :D], kv[:, D:], B, heads, N, M, d, d ** -0.5)
+        y = ops.gemm_nt(ops.EPI_F32, o, wp, proj_b)
+        ctx.saved = (xb, cb, q, kv, o, lse, wqt, wkvt, wpt, (q_w, q_b, kv_w, kv_b, proj_w, proj_b), (B, N, M, D, heads))
+        return y.reshape(B, N, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        xb, cb, q, kv, o, lse, wqt, wkvt, wpt, (q_w, q_b, kv_w, kv_b, proj_w, proj_b), (B, N, M, D, heads) = ctx.saved
+        ctx.saved = None
+        d = D // heads
+        gb = _bf16(g.contiguous().reshape(B * N, D))
+        d_o = ops.gemm_nt(ops.EPI_BF16, gb, wpt, None)
+        dwp, dbp = _lin_grads(gb, o, proj_w, proj_b)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        ops.attn_bwd(q, kv[:, :D], kv[:, D:], o, d_o, lse, dq, dkv[:, :D], dkv[:, D:], B, heads, N, M, d, d ** -0.5)
+        dx = ops.gemm_nt(ops.EPI_F32, dq, wqt, None)
+        dctx = ops.gemm_nt(ops.EPI_F32, dkv, wkvt, None)
+        dwq, dbq = _lin_grads(dq, xb, q_w, q_b)
+        dwkv, dbkv = _lin_grads(dkv, cb, kv_w, kv_b)
+        return dx.reshape(B, N, D), dctx.reshape(B, M, D), None, dwq, dbq, dwkv, dbkv, dwp, dbp
+
+
+# ---------------------------------------------------------------------------------------------
 # input side: masks, patch projection of the kept tokens, global tokens
 # ---------------------------------------------------------------------------------------------
 def round_up(v: int, m: int) -> int:

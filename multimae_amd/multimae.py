@@ -210,6 +210,46 @@ class MultiMAE(nn.Module):
         return preds, task_masks
 
 
+class MultiViT(MultiMAE):
+    """MultiMAE without masking: every token of every given domain plus the global tokens goes through the encoder
+    (reference: multimae/multimae.py:481-574).  With output_adapters=None it returns the encoder tokens [B, sum N + G, D]
+    (or the list of every layer's tokens with return_all_layers); output adapters, when given, are called as
+    adapter(encoder_tokens=..., input_info=...) like the reference's finetuning heads."""
+
+    def process_input(self, x):
+        x = {"rgb": x} if isinstance(x, torch.Tensor) else x
+        domains = [d for d in x if d in self.input_adapters]
+        adapters = [self.input_adapters[d] for d in domains]
+        ref_d = "rgb" if "rgb" in x else ("semseg" if "semseg" in x else domains[0])  # reference :505-514
+        B = x[ref_d].shape[0]
+        H, W = (s * (getattr(self.input_adapters[ref_d], "stride_level", 1) if ref_d == "semseg" else 1) for s in x[ref_d].shape[-2:])
+        grids = [ad.grid(*x[d].shape[-2:]) for d, ad in zip(domains, adapters)]
+        if any(g != grids[0] for g in grids):
+            raise NotImplementedError("all input domains must map to the same token grid")
+        nh, nw = grids[0]
+        device = x[domains[0]].device
+        specs = OrderedDict((d, torch.empty((B, nh * nw, 0), device=device)) for d in domains)
+        input_info = self.generate_input_info(specs, image_size=(H, W))
+        keep32 = torch.arange(nh * nw * len(domains), dtype=torch.int32, device=device).expand(B, -1).contiguous()
+        tokens = Fn.EmbedFn.apply(keep32, [ad.P_H for ad in adapters], (nh, nw), [ad.pos_table(nh, nw) for ad in adapters],
+                                  self.global_tokens, len(domains), *[x[d] for d in domains], *[ad.proj.weight for ad in adapters],
+                                  *[ad.proj.bias for ad in adapters], *[ad.class_table for ad in adapters])
+        return tokens, input_info
+
+    def forward(self, x: Union[Dict[str, torch.Tensor], torch.Tensor], return_all_layers=False, **kwargs):
+        input_tokens, input_info = self.process_input(x)
+        if not return_all_layers:
+            encoder_tokens = self.encoder(input_tokens)
+        else:
+            encoder_tokens, tokens = [], input_tokens
+            for block in self.encoder:
+                tokens = block(tokens)
+                encoder_tokens.append(tokens)
+        if self.output_adapters is None:
+            return encoder_tokens
+        return {d: self.output_adapters[d](encoder_tokens=encoder_tokens, input_info=input_info) for d in self.output_adapters}
+
+
 _MODEL_REGISTRY = {}
 
 
@@ -234,4 +274,16 @@ def pretrain_multimae_base(input_adapters: Dict[str, nn.Module], output_adapters
 @register_model
 def pretrain_multimae_large(input_adapters: Dict[str, nn.Module], output_adapters: Optional[Dict[str, nn.Module]], **kwargs):
     return MultiMAE(input_adapters=input_adapters, output_adapters=output_adapters, dim_tokens=1024, depth=24, num_heads=16,
+                    mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+@register_model
+def multivit_base(input_adapters: Dict[str, nn.Module], output_adapters: Optional[Dict[str, nn.Module]], **kwargs):
+    return MultiViT(input_adapters=input_adapters, output_adapters=output_adapters, dim_tokens=768, depth=12, num_heads=12,
+                    mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+@register_model
+def multivit_large(input_adapters: Dict[str, nn.Module], output_adapters: Optional[Dict[str, nn.Module]], **kwargs):
+    return MultiViT(input_adapters=input_adapters, output_adapters=output_adapters, dim_tokens=1024, depth=24, num_heads=16,
                     mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)

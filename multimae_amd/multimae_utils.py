@@ -58,8 +58,8 @@ class DropPath(nn.Module):
 
 
 class Mlp(nn.Module):
-    """fc1 -> exact GELU -> fc2 (reference: multimae/multimae_utils.py:145-169). Parameter container; the enclosing
-    Block / SpatialOutputAdapter runs it fused with its LayerNorm and residual."""
+    """fc1 -> exact GELU -> fc2 (reference: multimae/multimae_utils.py:145-169).  Inside Block / SpatialOutputAdapter it
+    runs fused with the LayerNorm and residual around it; called directly it is the bare two-GEMM chain."""
 
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
         super().__init__()
@@ -68,6 +68,9 @@ class Mlp(nn.Module):
             raise NotImplementedError("only nn.GELU (erf form) is fused into the GEMM epilogue")
         self.fc1 = nn.Linear(in_features, hidden_features or in_features)
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+    def forward(self, x):
+        return Fn.MlpFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
 
 
 class Attention(nn.Module):
@@ -81,6 +84,9 @@ class Attention(nn.Module):
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim)
 
+    def forward(self, x):
+        return Fn.AttentionFn.apply(x, self.num_heads, self.qkv.weight, _bias_or_zeros(self.qkv), self.proj.weight, self.proj.bias)
+
 
 class CrossAttention(nn.Module):
     """q / kv / proj parameters of multi-head cross-attention (reference: multimae/multimae_utils.py:210-247)."""
@@ -93,6 +99,10 @@ class CrossAttention(nn.Module):
         self.q = nn.Linear(dim, dim, bias=qkv_bias)
         self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x, context):
+        return Fn.CrossAttentionFn.apply(x, context, self.num_heads, self.q.weight, _bias_or_zeros(self.q), self.kv.weight,
+                                         _bias_or_zeros(self.kv), self.proj.weight, self.proj.bias)
 
 
 def _bias_or_zeros(lin: nn.Linear):

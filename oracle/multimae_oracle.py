@@ -410,6 +410,20 @@ def forward(sd: Dict[str, Tensor], cfg: dict, x: Dict[str, Tensor], task_samplin
     return preds, mask_d
 
 
+def multivit_forward(sd: Dict[str, Tensor], cfg: dict, x: Dict[str, Tensor], return_all_layers: bool = False):
+    """MultiViT encoder pass: all tokens of the given domains + global tokens, no masking (multimae/multimae.py:501-563)."""
+    names = [d for d in cfg["in_domains"] if d in x]
+    B = next(iter(x.values())).shape[0]
+    toks = [semseg_input_adapter(x[d], sd, f"input_adapters.{d}", domain_patch(cfg, d)) if d in cfg.get("num_classes", {})
+            else input_adapter(x[d], sd, f"input_adapters.{d}", domain_patch(cfg, d)) for d in names]
+    enc = torch.cat(toks + [sd["global_tokens"].expand(B, -1, -1)], dim=1)
+    layers = []
+    for i in range(cfg["depth"]):
+        enc = block(enc, sd, f"encoder.{i}", cfg["heads"])
+        layers.append(enc)
+    return layers if return_all_layers else enc
+
+
 # --------------------------------------------------------------------------
 # losses (multimae/criterion.py)
 # --------------------------------------------------------------------------

@@ -253,6 +253,42 @@ def gen_semseg_e2e(fname="small_semseg_e2e.npz"):
     print(fname, "ok; losses", {t: float(v) for t, v in losses.items()})
 
 
+def gen_multivit(fname="small_multivit.npz"):
+    """Reference MultiViT (no masking, all 2*16 tokens + global token through the encoder) on the small configuration."""
+    cfg = O.small_cfg()
+    sd = {k: v for k, v in G.perturbed_state(cfg, seed=7).items() if not k.startswith("output_adapters.")}
+    ia = {d: ref.PatchedInputAdapter(num_channels=C, stride_level=1, patch_size_full=cfg["patch"], image_size=cfg["image"])
+          for d, C in cfg["in_domains"].items()}
+    model = ref.MultiViT(ia, None, num_global_tokens=cfg["num_global"], dim_tokens=cfg["dim"], depth=cfg["depth"],
+                         num_heads=cfg["heads"])
+    model.load_state_dict(sd, strict=True)
+    x = G.seeded_inputs(cfg, B=2, seed=3)
+    layers = model(x, return_all_layers=True)
+    last = model(x)
+    assert torch.equal(last, layers[-1])
+    g = torch.Generator().manual_seed(77)
+    dy = torch.randn(last.shape, generator=g)
+    model.zero_grad()
+    last.backward(dy)
+    named = dict(model.named_parameters())
+    out = {"dy": dy.numpy(), "rgb_only": model({"rgb": x["rgb"]}).detach().numpy()}
+    for i, t in enumerate(layers):
+        out[f"layer{i}"] = t.detach().numpy()
+    for n in ("global_tokens", "input_adapters.depth.proj.weight", "encoder.0.attn.qkv.weight", "encoder.1.mlp.fc2.bias"):
+        out["grad_" + n] = named[n].grad.numpy()
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, "ok", tuple(last.shape))
+
+
+def gen_keys():
+    """Digest of the reference's downstream-export key list (utils/multimae_keys.py:4-156) and its length."""
+    from utils.multimae_keys import MULTIVIT_PRETRAINED_KEYS
+    digest = hashlib.sha256("\n".join(MULTIVIT_PRETRAINED_KEYS).encode()).digest()
+    np.savez_compressed(os.path.join(HERE, "keys.npz"), multivit_sha256=np.frombuffer(digest, dtype=np.uint8),
+                        multivit_count=np.int64(len(MULTIVIT_PRETRAINED_KEYS)))
+    print("keys ok", len(MULTIVIT_PRETRAINED_KEYS))
+
+
 def gen_schedule():
     import contextlib
     import io
@@ -361,6 +397,8 @@ if __name__ == "__main__":
         sys.exit(0)
     gen_semseg_e2e()
     gen_schedule()
+    gen_multivit()
+    gen_keys()
     gen_masks()
     gen_posemb()
     gen_tiny_e2e()

@@ -350,3 +350,121 @@ def test_pretrain_step_applies_schedules_and_clipping():
     named = dict(ref.named_parameters())
     worst = max(rel_err(p.detach(), named[n].detach()) for n, p in model.named_parameters() if p.requires_grad)
     assert worst < 2e-5, worst
+
+
+def test_standalone_mlp_attention_cross_attention_vs_oracle():
+    """Mlp, Attention and CrossAttention called directly (reference: multimae/multimae_utils.py:162-169, :191-207,
+    :224-247), forward and backward against the oracle's restatement."""
+    from multimae_amd.multimae_utils import Attention, CrossAttention, Mlp
+    from oracle import multimae_oracle as O
+    torch.manual_seed(31)
+    B, N, M, D, heads = 3, 50, 21, 128, 4
+    x = torch.randn(B, N, D); ctx = torch.randn(B, M, D); dy = torch.randn(B, N, D)
+
+    def run(mod, ref_fn, inputs):
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in mod.state_dict().items()}
+        ins = [t.clone().requires_grad_(True) for t in inputs]
+        y_ref = ref_fn(sd, *ins)
+        y_ref.backward(dy)
+        mod = mod.cuda()
+        gin = [t.cuda().requires_grad_(True) for t in inputs]
+        y = mod(*gin)
+        y.backward(dy.cuda())
+        errs = {"y": rel_err(y.detach().cpu(), y_ref.detach())}
+        for i, (a, b) in enumerate(zip(gin, ins)):
+            errs[f"din{i}"] = rel_err(a.grad.cpu(), b.grad)
+        for n, p in mod.named_parameters():
+            errs[n] = rel_err(p.grad.cpu(), sd[n].grad)
+        assert all(v < BF16_TOL for v in errs.values()), errs
+
+    mlp, att, xatt = Mlp(D, 4 * D), Attention(D, heads, qkv_bias=True), CrossAttention(D, heads, qkv_bias=True)
+    for m in (mlp, att, xatt):
+        for n, p in m.named_parameters():
+            torch.nn.init.normal_(p, std=0.08 if p.ndim > 1 else 0.02)
+    run(mlp, lambda sd, a: O._mlp(a, {"m." + k: v for k, v in sd.items()}, "m"), [x])
+    run(att, lambda sd, a: O.self_attention(a, {"a." + k: v for k, v in sd.items()}, "a", heads), [x])
+    run(xatt, lambda sd, a, c: O.cross_attention(a, c, {"x." + k: v for k, v in sd.items()}, "x", heads), [x, ctx])
+
+
+def test_multivit_encoder_vs_reference_golden():
+    import multimae_amd as M
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    z = G.load("small_multivit.npz")
+    cfg = O.small_cfg()
+    sd = {k: v for k, v in G.perturbed_state(cfg, seed=7).items() if not k.startswith("output_adapters.")}
+    ia = {d: M.PatchedInputAdapter(num_channels=C, stride_level=1, patch_size_full=cfg["patch"], image_size=cfg["image"])
+          for d, C in cfg["in_domains"].items()}
+    model = M.MultiViT(ia, None, num_global_tokens=cfg["num_global"], dim_tokens=cfg["dim"], depth=cfg["depth"], num_heads=cfg["heads"])
+    model.load_state_dict(sd, strict=True)
+    model.cuda()
+    x = {d: t.cuda() for d, t in G.seeded_inputs(cfg, B=2, seed=3).items()}
+    layers = model(x, return_all_layers=True)
+    assert len(layers) == cfg["depth"] and layers[-1].shape == (2, 33, cfg["dim"])
+    for i, t in enumerate(layers):
+        assert rel_err(t.detach().cpu(), z[f"layer{i}"]) < BF16_TOL, i
+    model.zero_grad(set_to_none=True)
+    last = model(x)
+    assert torch.equal(last, layers[-1])
+    last.backward(torch.from_numpy(z["dy"]).cuda())
+    named = dict(model.named_parameters())
+    for n in ("global_tokens", "input_adapters.depth.proj.weight", "encoder.0.attn.qkv.weight", "encoder.1.mlp.fc2.bias"):
+        assert rel_err(named[n].grad.cpu(), z["grad_" + n]) < BF16_TOL, n
+    assert rel_err(model({"rgb": x["rgb"]}).detach().cpu(), z["rgb_only"]) < BF16_TOL
+    assert isinstance(M.create_model("multivit_base", input_adapters=ia, output_adapters=None), M.MultiViT)
+
+
+def test_checkpoint_round_trip_and_optimizer_interchange(tmp_path):
+    """save_model / auto_load_model reproduce the training state exactly; the optimizer entry loads into
+    torch.optim.AdamW (and back); the downstream export holds the encoder-side tensors only."""
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    from multimae_amd import checkpoint as CK
+    from multimae_amd.train import PretrainStep, split_decay
+    cfg = O.small_cfg()
+    sd = G.perturbed_state(cfg, seed=7)
+    x = {d: t.cuda() for d, t in G.seeded_inputs(cfg, B=4, seed=3).items()}
+    rnd = O.draw_mask_randomness(4, [16, 16], 1.0, torch.Generator().manual_seed(2))
+
+    def fresh():
+        m = _build(cfg); m.load_state_dict(sd); m.cuda()
+        return m, PretrainStep(m, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05)
+    model, step = fresh()
+    for _ in range(2):
+        step(x, mask_randomness=rnd)
+    path = CK.save_model(str(tmp_path), 4, model, step.opt)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(ck) == {"model", "optimizer", "epoch", "scaler", "args"} and set(ck["model"]) == set(sd)
+
+    model2, step2 = fresh()
+    assert CK.auto_load_model(str(tmp_path), model2, step2.opt) == 5
+    l1, _, _ = step(x, mask_randomness=rnd)
+    l2, _, _ = step2(x, mask_randomness=rnd)
+    assert torch.equal(l1, l2)
+    assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), model2.state_dict().values()))
+
+    # the optimizer entry is a torch.optim.AdamW state_dict over [decayed, not decayed]
+    model3, _ = fresh()
+    model3.load_state_dict(ck["model"])
+    decay, no_decay = split_decay(model3)
+    topt = torch.optim.AdamW([{"params": [p for _, p in decay], "weight_decay": 0.05},
+                              {"params": [p for _, p in no_decay], "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.95))
+    topt.load_state_dict(ck["optimizer"])
+    _hip_step(model3, cfg, {d: t.cpu() for d, t in x.items()}, rnd, 8)
+    topt.step()
+    named = dict(model.named_parameters())
+    worst = max(rel_err(p.detach(), named[n].detach()) for n, p in model3.named_parameters() if p.requires_grad)
+    assert worst < 2e-5, worst
+    # and back: torch's state into the flat optimizer
+    model4, step4 = fresh()
+    model4.load_state_dict({k: v.detach().cpu() for k, v in model3.state_dict().items()})
+    step4.flat.sync_bf16()
+    CK.load_optimizer_state_dict(step4.opt, model4, topt.state_dict())
+    assert step4.opt.step_count == 3
+    l3, _, _ = step(x, mask_randomness=rnd)
+    l4, _, _ = step4(x, mask_randomness=rnd)
+    assert abs(l3.item() - l4.item()) / abs(l3.item()) < 1e-4
+
+    exp = torch.load(CK.save_model_for_downstream_tasks(str(tmp_path), "run", 4, model), map_location="cpu", weights_only=True)
+    assert list(exp) == ["model"] and not any(k.startswith("output_adapters.") for k in exp["model"])
+    assert set(exp["model"]) == {k for k in sd if not k.startswith("output_adapters.")}

@@ -168,3 +168,15 @@ def test_grad_buckets_world2_gloo(tmp_path):
     data = torch.randn(2, 5, 8, generator=g)
     (m(data[0]).pow(2).sum() + m(data[1]).pow(2).sum()).backward()
     assert torch.allclose(summed, flat.grads, rtol=1e-5, atol=1e-6)
+
+
+def test_downstream_export_keys_match_reference_list():
+    import hashlib
+    import numpy as np
+    from multimae_amd.builders import build_multimae
+    from multimae_amd.checkpoint import multivit_pretrained_keys
+    from tests.golden import common as G
+    z = G.load("keys.npz")
+    keys = multivit_pretrained_keys(build_multimae().state_dict().keys())
+    assert len(keys) == int(z["multivit_count"])
+    assert hashlib.sha256("\n".join(keys).encode()).digest() == z["multivit_sha256"].tobytes()

@@ -182,3 +182,17 @@ def test_depth_standardisation():
     z = G.load("depth_std.npz")
     out = O.standardize_depth(torch.from_numpy(z["depth"]))
     assert rel_err(out, z["out"]) < 1e-6
+
+
+def test_multivit_encoder_pass():
+    z = G.load("small_multivit.npz")
+    cfg = O.small_cfg()
+    sd = {k: v.clone().requires_grad_(not k.endswith(O.FROZEN_SUFFIX)) for k, v in G.perturbed_state(cfg, seed=7).items()}
+    x = G.seeded_inputs(cfg, B=2, seed=3)
+    layers = O.multivit_forward(sd, cfg, x, return_all_layers=True)
+    for i, t in enumerate(layers):
+        assert rel_err(t.detach(), z[f"layer{i}"]) < FP32_TOL, i
+    layers[-1].backward(torch.from_numpy(z["dy"]))
+    for n in ("global_tokens", "input_adapters.depth.proj.weight", "encoder.0.attn.qkv.weight", "encoder.1.mlp.fc2.bias"):
+        assert rel_err(sd[n].grad, z["grad_" + n]) < FP32_TOL, n
+    assert rel_err(O.multivit_forward(sd, cfg, {"rgb": x["rgb"]}).detach(), z["rgb_only"]) < FP32_TOL
