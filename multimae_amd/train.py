@@ -180,16 +180,42 @@ class FlatAdamW:
 
     def __init__(self, flat: FlatParams, lr=1e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05):
         self.flat = flat
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        # the two groups of the flat layout, writable like torch's (the reference's loop assigns "lr" and
+        # "weight_decay" per iteration, run_pretraining_multimae.py:427-436); one learning rate serves both
+        self.param_groups = [{"lr": lr, "weight_decay": weight_decay, "lr_scale": 1.0, "betas": betas, "eps": eps},
+                             {"lr": lr, "weight_decay": 0.0, "lr_scale": 1.0, "betas": betas, "eps": eps}]
+        self.betas, self.eps = betas, eps
         self.exp_avg = torch.zeros_like(flat.params)
         self.exp_avg_sq = torch.zeros_like(flat.params)
         self.step_count = 0   # calls of step()
         self.step_dev = None  # applied updates (device int32), created on the first step that may skip
 
+    @property
+    def lr(self) -> float:
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, v: float):
+        for g in self.param_groups:
+            g["lr"] = v
+
+    @property
+    def weight_decay(self) -> float:
+        return self.param_groups[0]["weight_decay"]
+
+    @weight_decay.setter
+    def weight_decay(self, v: float):
+        self.param_groups[0]["weight_decay"] = v
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat.zero_grad()
+
     def step(self, grad_scale: float = 1.0, clip_grad: Optional[float] = None, skip_grad: Optional[float] = None,
              grad_sumsq: Optional[torch.Tensor] = None):
         """grad_sumsq: device scalar sum(g^2) of the raw gradient buffer (computed here if clipping / skipping needs it).
         With skip_grad the number of applied updates lives on the device (no host synchronisation)."""
+        if self.param_groups[1]["lr"] != self.param_groups[0]["lr"]:
+            raise ValueError("FlatAdamW applies one learning rate to both parameter groups")
         self.step_count += 1
         if (clip_grad or skip_grad) and grad_sumsq is None:
             grad_sumsq = self.grad_norm_sq()

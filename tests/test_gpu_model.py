@@ -468,3 +468,34 @@ def test_checkpoint_round_trip_and_optimizer_interchange(tmp_path):
     exp = torch.load(CK.save_model_for_downstream_tasks(str(tmp_path), "run", 4, model), map_location="cpu", weights_only=True)
     assert list(exp) == ["model"] and not any(k.startswith("output_adapters.") for k in exp["model"])
     assert set(exp["model"]) == {k for k in sd if not k.startswith("output_adapters.")}
+
+
+def test_reference_style_loop_with_utils_helpers():
+    """The reference's loop shape (zero_grad, loss_scaler(loss, optimizer, clip_grad=..., parameters=...), per-iteration
+    param_group["lr"]) over create_optimizer / NativeScalerWithGradNormCount equals PretrainStep."""
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    from multimae_amd import utils as U
+    from multimae_amd.train import PretrainStep
+    cfg = O.small_cfg()
+    sd = G.perturbed_state(cfg, seed=7)
+    x = {d: t.cuda() for d, t in G.seeded_inputs(cfg, B=4, seed=3).items()}
+    rnd = O.draw_mask_randomness(4, [16, 16], 1.0, torch.Generator().manual_seed(2))
+    lrs = U.cosine_scheduler(1e-3, 1e-5, 1, 3)
+    a = _build(cfg); a.load_state_dict(sd); a.cuda()
+    step = PretrainStep(a, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05, clip_grad=0.5, lr_schedule_values=lrs)
+    b = _build(cfg); b.load_state_dict(sd); b.cuda()
+    optimizer, buckets = U.create_optimizer(b, lr=1e-3, weight_decay=0.05)
+    loss_scaler = U.NativeScalerWithGradNormCount(buckets=buckets)
+    fns = _losses(cfg)
+    for it in range(3):
+        la, _, gn2 = step(x, mask_randomness=rnd)
+        for group in optimizer.param_groups:
+            group["lr"] = lrs[it] * group["lr_scale"]
+        preds, masks = b(x, num_encoded_tokens=8, alphas=1.0, mask_randomness=rnd)
+        loss = sum(fn(preds[t].float(), x[tg], mask=masks[tg]) for t, (fn, tg) in fns.items())
+        optimizer.zero_grad()
+        norm = loss_scaler(loss, optimizer, clip_grad=0.5, parameters=b.parameters())
+        assert torch.equal(loss.detach(), la) and torch.equal(norm, gn2.sqrt())
+    assert all(torch.equal(p, q) for p, q in zip(a.state_dict().values(), b.state_dict().values()))
+    assert U.get_rank() == 0 and U.get_world_size() == 1 and U.is_main_process()
