@@ -51,7 +51,8 @@ int mmae_gemm_nt(int epi, const void* A, long lda, const void* W, long ldw, int 
 
 /* Kernel choice for mmae_gemm_nt and its two siblings below: 0 = by problem size (default), 1 = always the 128x128
  * two-workgroups-per-CU kernel, 2 = persistent 256x128 (3-stage ring), 3 = persistent 256x128 with 32-deep stages,
- * 4 = persistent 128x128 (2-stage ring).  Process-wide; for tests and tuning. */
+ * 4 = persistent 128x128 (2-stage ring), 5 = 256x256 eight-wave ping-pong kernel (K a multiple of 128, else as 0).
+ * Process-wide; for tests and tuning. */
 void mmae_gemm_nt_set_variant(int variant);
 
 /* Patch projection of the kept tokens only: out[(m/seg_in)*seg_out + m%seg_in] = A[m] x W^T + add_tab[add_idx[m]]

@@ -6,6 +6,7 @@
 // Both use 128x128 output tiles, four waves (2x2, 64x64 each), v_mfma_f32_16x16x32_bf16,
 // 16-byte global->LDS DMA into a double-buffered, XOR-swizzled LDS image.
 #include "common.h"
+#include <type_traits>
 
 #define BM 128
 #define BN 128
@@ -39,10 +40,38 @@ struct GemmNT {
 };
 
 // Stores one wave's 64x64 accumulator block: (acc[2u][mi], acc[2u+1][mi]) = C[m = mw + mi*16 + fr][n = nw + 32*u + 8*fq + 0..7]
+// bias_regs (optional): the lane's 16 bias values, [8*u + e] = bias[nw + 32*u + 8*fq + e], for callers that cannot afford a
+// global load in the epilogue (an ordinary load's result makes the compiler drain every LDS-DMA in flight).
 template <int EPI>
-__device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&acc)[4][4], int mw, int nw, int fr, int fq) {
+__device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&acc)[4][4], int mw, int nw, int fr, int fq,
+                                                const float* bias_regs = nullptr) {
+    // Epilogue inputs (residual / saved pre-activation) are fetched for the whole 64x64 block before anything is stored:
+    // a load issued after a store has to wait for that store as well (one in-order counter), which would serialise
+    // sixteen memory round trips.
+    constexpr int MB = EPI == EPI_RESID ? 2 : 4;  // fragment rows per batch (register budget: 16 / 8 registers per row)
+    f32x4 res[EPI == EPI_RESID ? MB : 1][2][2];
+    bf16x8 hsv[EPI == EPI_DGELU ? MB : 1][2];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
+        if ((EPI == EPI_RESID || EPI == EPI_DGELU) && mi % MB == 0) {
+#pragma unroll
+            for (int mj = 0; mj < MB; ++mj) {
+                int m = mw + (mi + mj) * 16 + fr;
+                m = m < p.M ? m : p.M - 1;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    int n = nw + 32 * u + 8 * fq;
+                    n = n < p.N ? n : p.N - 8;
+                    if (EPI == EPI_RESID) {
+                        const float* rp = (const float*)p.aux + (long)m * p.ldaux + n;
+                        res[EPI == EPI_RESID ? mj : 0][u][0] = *(const f32x4*)rp;
+                        res[EPI == EPI_RESID ? mj : 0][u][1] = *(const f32x4*)(rp + 4);
+                    } else {
+                        hsv[EPI == EPI_DGELU ? mj : 0][u] = *(const bf16x8*)((const bf16*)p.aux + (long)m * p.ldaux + n);
+                    }
+                }
+            }
+        }
         const int m = mw + mi * 16 + fr;
         if (m >= p.M) continue;
         long orow = m;
@@ -66,9 +95,14 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = acc[2 * u][mi][e]; v[4 + e] = acc[2 * u + 1][mi][e]; }
             if (EPI != EPI_DGELU && EPI != EPI_TOKENS && p.bias) {
-                const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+                if (bias_regs) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                    for (int e = 0; e < 8; ++e) v[e] += bias_regs[8 * u + e];
+                } else {
+                    const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                }
             }
             if (EPI == EPI_BF16) {
                 bf16x8 o;
@@ -82,13 +116,12 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
                 *(bf16x8*)((bf16*)p.out + orow * p.ldo + n) = h;
                 *(bf16x8*)((bf16*)p.out2 + orow * p.ldo + n) = g;
             } else if (EPI == EPI_RESID) {
-                const float* rp = (const float*)p.aux + orow * p.ldaux + n;
-                const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+                const f32x4 r0 = res[EPI == EPI_RESID ? mi % MB : 0][u][0], r1 = res[EPI == EPI_RESID ? mi % MB : 0][u][1];
                 float* op = (float*)p.out + orow * p.ldo + n;
                 *(f32x4*)op = (f32x4){r0[0] + v[0], r0[1] + v[1], r0[2] + v[2], r0[3] + v[3]};
                 *(f32x4*)(op + 4) = (f32x4){r1[0] + v[4], r1[1] + v[5], r1[2] + v[6], r1[3] + v[7]};
             } else if (EPI == EPI_DGELU) {
-                const bf16x8 h = *(const bf16x8*)((const bf16*)p.aux + orow * p.ldaux + n);
+                const bf16x8 h = hsv[EPI == EPI_DGELU ? mi % MB : 0][u];
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16)(v[e] * gelu_erf_grad((float)h[e]));
@@ -487,6 +520,222 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_persist32_kernel(GemmNT p, int
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// 256x256x64 persistent kernel, eight waves (2 along M x 4 along N, 128x64 outputs each = 128 accumulator registers),
+// one workgroup per CU.  Each k-tile is staged as four 16-KiB half-tiles ("slots") by 16-byte LDS-DMA, two instructions
+// per thread and slot, one slot per phase, seven half-tiles ahead of the phase that computes, with a counted vmcnt once
+// per k-tile and raw s_barriers so the loads stay in flight across barriers.  A k-tile is computed in four phases, one
+// 64x32 quadrant of the wave's block each (16 MFMAs):
+//   phase 0: read A rows 0-63 (slot 0, 8 reads) and W rows 0-31 (slot 1, 4 reads)   -> quadrant (A-lo, W-lo)
+//   phase 1: read W rows 32-63 (slot 2, 4 reads)                                     -> (A-lo, W-hi)
+//   phase 2: read A rows 64-127 (slot 3, 8 reads)                                    -> (A-hi, W-hi)
+//   phase 3: no reads (W-lo stays in registers)                                      -> (A-hi, W-lo)
+// so slot s is last read in phase <= s and can be refilled from phase s + 1 on: phase q stages slot (q + 3) % 4.
+// The two wave groups (wm = 0 / 1, one wave of each per SIMD) run one barrier apart: while one group issues its LDS
+// reads and loads, the other runs its MFMA cluster.
+// Slot images: 128 rows x 128 B; slot 0 / 3 hold activation rows {wm*128 + (0|64) + 0..63}, slot 1 / 2 weight rows
+// {wn*64 + (0|32) + 0..31}; 16-byte chunk c of row r sits at c ^ swz(r) (same two swizzles as the 128x128 kernel).
+// Requires K % 128 == 0 (k-tiles come in pairs, one per LDS buffer).
+// ------------------------------------------------------------------------------------------
+#define PP_H_BYTES 16384
+#define PP_KT_BYTES (4 * PP_H_BYTES)
+#define PP_LDS (2 * PP_KT_BYTES + 8 * 256)  // + per-wave bias slice (64 floats)
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char ppsmem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4, swz = fr >> 1;
+    const int ntiles = tiles_m * tiles_n, G = gridDim.x;
+    const int me = xcd_remap(blockIdx.x, G);
+    const int nk = p.K >> 6;
+    if (me >= ntiles) return;
+    const int my_tiles = (ntiles - 1 - me) / G + 1;
+    const int total_kt = my_tiles * nk;
+    float* bias_lds = (float*)(ppsmem + 2 * PP_KT_BYTES) + wave * 64;
+
+    auto tile_origin = [&](int t, int& m0, int& n0) {  // groups of 4 row-tiles x all column-tiles, rows fastest
+        const int per_group = 4 * tiles_n;
+        const int grp = t / per_group, within = t - grp * per_group;
+        int rows = tiles_m - grp * 4; rows = rows < 4 ? rows : 4;
+        m0 = (grp * 4 + within % rows) * 256;
+        n0 = (within / rows) * 256;
+    };
+
+    // ---- staging cursors: one per slot (slot 3 runs one k-tile behind slots 0-2) ----
+    const bf16* src[4][2];
+    int s_kt[4], s_tile[4];
+    auto set_slot = [&](auto slot_c, int t) {
+        constexpr int s = decltype(slot_c)::value;
+        int m0, n0;
+        tile_origin(t, m0, n0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (j * 8 + wave) * 8 + (lane >> 3);
+            if (s == 0 || s == 3) {
+                int g = m0 + (r >> 6) * 128 + (s == 3 ? 64 : 0) + (r & 63);
+                g = g < p.M ? g : p.M - 1;
+                src[s][j] = p.A + (long)g * p.lda + (((lane & 7) ^ ((r >> 1) & 7)) << 3);
+            } else {
+                int g = n0 + (r >> 5) * 64 + (s == 2 ? 32 : 0) + (r & 31);
+                g = g < p.N ? g : p.N - 1;
+                src[s][j] = p.W + (long)g * p.ldw + (((lane & 7) ^ (((r >> 1) & 1) | (((r >> 3) & 3) << 1))) << 3);
+            }
+        }
+    };
+    auto stage_slot = [&](auto slot_c) {
+        constexpr int s = decltype(slot_c)::value;
+        char* dst = ppsmem + (s_kt[s] & 1) * PP_KT_BYTES + s * PP_H_BYTES + wave * 1024;
+        glds16(src[s][0], dst);
+        glds16(src[s][1], dst + 8 * 1024);
+        if (s_tile[s] < ntiles) {
+            src[s][0] += 64; src[s][1] += 64;
+            if (++s_kt[s] == nk) {
+                s_kt[s] = 0;
+                s_tile[s] += G;
+                if (s_tile[s] < ntiles) {
+                    set_slot(slot_c, s_tile[s]);
+                } else {  // end of this workgroup's stream: the run-ahead copies read the zero page (never consumed)
+                    src[s][0] = src[s][1] = (const bf16*)g_zero_page;
+                }
+            }
+        } else {
+            s_kt[s] ^= 1;  // keep alternating buffers so the write lands in the slot that is free
+        }
+    };
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { s_kt[s] = 0; s_tile[s] = me; }
+    set_slot(S0{}, me); set_slot(S1{}, me); set_slot(S2{}, me); set_slot(S3{}, me);
+
+    // ---- prologue: 7 half-tiles in flight, the first k-tile landed ----
+    stage_slot(S0{}); stage_slot(S1{}); stage_slot(S2{}); stage_slot(S3{});
+    stage_slot(S0{}); stage_slot(S1{}); stage_slot(S2{});
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 acc[2][4][4];  // [A half][weight fragment][activation fragment]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 af[4][2], wlo[2][2], whi[2][2];
+    const int a_off = (wm * 64 + fr) * 128;                                 // + mi * 2048
+    const int w_off = (wn * 32 + 8 * (fr >> 2) + (fr & 3)) * 128;           // + t * 512
+    const int ch0 = ((fq ^ swz) << 4), ch1 = (((4 + fq) ^ swz) << 4);
+
+    auto read_a = [&](const char* slot) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            af[mi][0] = *(const bf16x8*)(slot + a_off + mi * 2048 + ch0);
+            af[mi][1] = *(const bf16x8*)(slot + a_off + mi * 2048 + ch1);
+        }
+    };
+    auto read_w = [&](const char* slot, bf16x8 (&w)[2][2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            w[t][0] = *(const bf16x8*)(slot + w_off + t * 512 + ch0);
+            w[t][1] = *(const bf16x8*)(slot + w_off + t * 512 + ch1);
+        }
+    };
+    auto mfma_quad = [&](f32x4 (&c)[4][4], int nbase, const bf16x8 (&w)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    c[nbase + t][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[t][ks], af[mi][ks], c[nbase + t][mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // second wave group runs one barrier behind
+
+    int tile = me, kt = 0;
+    for (int T = 0; T < total_kt; T += 2) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const char* buf = ppsmem + b * PP_KT_BYTES;
+            // ---- phase 0 ----
+            read_a(buf);
+            read_w(buf + PP_H_BYTES, wlo);
+            if (kt == 0 && b == 0 && p.bias) {  // this tile's bias slice for the wave (256 B), older than every wait below
+                int m0, n0;
+                tile_origin(tile, m0, n0);
+                int n = n0 + wn * 64 + lane; n = n < p.N ? n : p.N - 1;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + n),
+                                                 (__attribute__((address_space(3))) void*)bias_lds, 4, 0, 0);
+            }
+            stage_slot(S3{});
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // the slot-0 reads are done before the barrier: slot 0 is refilled next phase
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_quad(acc[0], 0, wlo);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 1 ----
+            read_w(buf + 2 * PP_H_BYTES, whi);
+            stage_slot(S0{});
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_quad(acc[0], 2, whi);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 2 ----
+            read_a(buf + 3 * PP_H_BYTES);
+            stage_slot(S1{});
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_quad(acc[1], 2, whi);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 3 ----
+            stage_slot(S2{});
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // all but the newest three half-tiles: the next k-tile has landed
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_quad(acc[1], 0, wlo);
+            __builtin_amdgcn_s_barrier();
+        }
+        kt += 2;
+        if (kt == nk) {
+            int m0, n0;
+            tile_origin(tile, m0, n0);
+            float bv[16];
+            if (p.bias) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const f32x4 b0 = *(const f32x4*)(bias_lds + 32 * u + 8 * fq), b1 = *(const f32x4*)(bias_lds + 32 * u + 8 * fq + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bv[8 * u + e] = b0[e]; bv[8 * u + 4 + e] = b1[e]; }
+                }
+            }
+            store_wave_tile<EPI>(p, acc[0], m0 + wm * 128, n0 + wn * 64, fr, fq, bv);
+            store_wave_tile<EPI>(p, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, fr, fq, bv);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            kt = 0;
+            tile += G;
+        }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();  // pairs with the extra barrier of the second group
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead loads past the end of the stream
+}
+
+template <int EPI>
+static int launch_nt_pp(const GemmNT& p, hipStream_t s);
+
 static int g_num_cus = 0;
 static int num_cus() {
     if (g_num_cus == 0) {
@@ -541,16 +790,44 @@ static int launch_nt_persist32(const GemmNT& p, hipStream_t s) {
     return MMAE_OK;
 }
 
+template <int EPI>
+static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
+    static bool reserved = false;
+    if (!reserved) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        if (e != hipSuccess) {
+            mmae_set_error("gemm_nt: cannot reserve %d bytes of LDS: %s", PP_LDS, hipGetErrorString(e));
+            return MMAE_ELAUNCH;
+        }
+        reserved = true;
+    }
+    const int tm = (p.M + 255) / 256, tn = (p.N + 255) / 256;
+    int grid = tm * tn;
+    if (grid > num_cus()) grid = num_cus();
+    hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(grid), dim3(512), PP_LDS, s, p, tm, tn);
+    MMAE_CHECK_LAUNCH("gemm_nt_pp");
+    return MMAE_OK;
+}
+
 static int g_nt_variant = 0;  // 0 = choose by size, 1 = always 128x128, 2 = always persistent 256x128
 extern "C" void mmae_gemm_nt_set_variant(int v) { g_nt_variant = v; }
 
 template <int EPI>
 static int launch_nt(const GemmNT& p, hipStream_t s) {
-    // Measured on MI355X at the shapes of the ViT-B step: the persistent 128x128 ring wins where a workgroup gets many
-    // tiles of a short K loop (N >= 2048: +6..11 %), the plain 128x128 grid elsewhere; the 256-row rings are slower.
+    // Measured on MI355X at the shapes of the ViT-B step.  The 256x256 ping-pong kernel runs a k-tile in about 60 % of the
+    // time the 128x128 kernels need per FLOP, but a workgroup owns a whole CU, so it pays only where the tile count
+    // fills the last round of CUs (N = 2304 / 3072 at M = 25344: 87 / 93 %; N = 768: 58 %, where it loses).  Among the
+    // 128x128 kernels the persistent ring wins for many tiles of a short K loop (N >= 2048), the plain grid elsewhere.
     const long tiles128 = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    if (g_nt_variant == 5 && p.K % 128 == 0) return launch_nt_pp<EPI>(p, s);
     if (g_nt_variant == 2) return launch_nt_persist<EPI, 4, 3>(p, s);
     if (g_nt_variant == 3) return launch_nt_persist32<EPI>(p, s);
+    if (g_nt_variant == 0 && p.K % 128 == 0 && EPI != EPI_RESID && EPI != EPI_TOKENS && EPI != EPI_UNPATCH) {
+        const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+        const long rounds = (tiles256 + num_cus() - 1) / num_cus();
+        const double fill = (double)tiles256 / (double)(rounds * num_cus());
+        if ((fill >= 0.85 && p.K >= 512) || (fill >= 0.75 && p.K >= 1024)) return launch_nt_pp<EPI>(p, s);
+    }
     if (g_nt_variant == 4 || (g_nt_variant == 0 && p.N >= 2048 && tiles128 >= 4 * 2 * num_cus()))
         return launch_nt_persist<EPI, 2, 2>(p, s);
     const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;

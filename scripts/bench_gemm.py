@@ -21,39 +21,40 @@ def r(*s, dt=torch.bfloat16):
     return (torch.randn(*s, device="cuda") * 0.5).to(dt)
 
 
-M = 25344
-shapes_nt = [("qkv", M, 2304, 768, 0), ("proj+res", M, 768, 768, 2), ("fc1+gelu", M, 3072, 768, 1), ("fc2+res", M, 768, 3072, 2),
-             ("dgelu", M, 3072, 768, 3), ("dLN fc1", M, 768, 3072, 0), ("dec fc1", 50176, 1024, 256, 1), ("dec qkv", 50176, 768, 256, 0),
-             ("dec fc2", 50176, 256, 1024, 2), ("pctx", M, 256, 768, 0)]
-for name, m, n, k, epi in shapes_nt:
-    a, w = r(m, k), r(n, k)
-    bias = torch.randn(n, device="cuda")
-    aux = r(m, n, dt=torch.float32) if epi == 2 else (r(m, n) if epi == 3 else None)
-    res = []
-    for variant in (1, 2, 3, 4):
-        ops._L().mmae_gemm_nt_set_variant(variant)
-        t = timeit(lambda: ops.gemm_nt(epi, a, w, None if epi == 3 else bias, aux=aux))
-        res.append(f"{t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
-    ops._L().mmae_gemm_nt_set_variant(0)
-    print(f"gemm_nt {name:10s} M={m} N={n} K={k}: t128 {res[0]} | p256 {res[1]} | p256k32 {res[2]} | p128 {res[3]}")
-if len(sys.argv) > 1 and sys.argv[1] == "nt":
-    sys.exit(0)
-for name, m, n, k in [("dW qkv", M, 2304, 768), ("dW proj", M, 768, 768), ("dW fc1", M, 3072, 768), ("dW fc2", M, 768, 3072),
-                      ("dW dec fc1", 50176, 1024, 256), ("dW dec proj", 50176, 256, 256)]:
-    x, y = r(m, n), r(m, k)
-    out = torch.zeros(n, k, device="cuda"); cs = torch.zeros(n, device="cuda")
-    t = timeit(lambda: ops.gemm_tn(x, y, out=out, accumulate=True, colsum_out=cs, colsum_accumulate=True))
-    print(f"gemm_tn {name:10s} M={m} N={n} K={k}: {t*1e6:8.1f} us  {2*m*n*k/t/1e12:7.1f} TF")
-for name, B, H, nq, nk, d in [("enc", 256, 12, 99, 99, 64), ("dec self", 256, 8, 196, 196, 32), ("dec cross", 256, 8, 196, 99, 32)]:
-    if nq == nk:
-        qkv = r(B * nq, 3 * H * d); q, k_, v = qkv[:, :H*d], qkv[:, H*d:2*H*d], qkv[:, 2*H*d:]
-        dqkv = torch.empty_like(qkv); dq, dk, dv = dqkv[:, :H*d], dqkv[:, H*d:2*H*d], dqkv[:, 2*H*d:]
-    else:
-        q = r(B * nq, H * d); kv = r(B * nk, 2 * H * d); k_, v = kv[:, :H*d], kv[:, H*d:]
-        dq = torch.empty_like(q); dkv = torch.empty_like(kv); dk, dv = dkv[:, :H*d], dkv[:, H*d:]
-    o, lse = ops.attn_fwd(q, k_, v, B, H, nq, nk, d, d ** -0.5)
-    do = r(B * nq, H * d)
-    t = timeit(lambda: ops.attn_fwd(q, k_, v, B, H, nq, nk, d, d ** -0.5))
-    t2 = timeit(lambda: ops.attn_bwd(q, k_, v, o, do, lse, dq, dk, dv, B, H, nq, nk, d, d ** -0.5))
-    fl = 4.0 * B * H * nq * nk * d
-    print(f"attn {name:10s}: fwd {t*1e6:7.1f} us {fl/t/1e12:6.1f} TF | bwd {t2*1e6:7.1f} us {2*fl/t2/1e12:6.1f} TF")
+if __name__ == "__main__":
+    M = 25344
+    shapes_nt = [("qkv", M, 2304, 768, 0), ("proj+res", M, 768, 768, 2), ("fc1+gelu", M, 3072, 768, 1), ("fc2+res", M, 768, 3072, 2),
+                 ("dgelu", M, 3072, 768, 3), ("dLN fc1", M, 768, 3072, 0), ("dec fc1", 50176, 1024, 256, 1), ("dec qkv", 50176, 768, 256, 0),
+                 ("dec fc2", 50176, 256, 1024, 2), ("pctx", M, 256, 768, 0)]
+    for name, m, n, k, epi in shapes_nt:
+        a, w = r(m, k), r(n, k)
+        bias = torch.randn(n, device="cuda")
+        aux = r(m, n, dt=torch.float32) if epi == 2 else (r(m, n) if epi == 3 else None)
+        res = []
+        for variant in (1, 2, 3, 4, 5):
+            ops._L().mmae_gemm_nt_set_variant(variant)
+            t = timeit(lambda: ops.gemm_nt(epi, a, w, None if epi == 3 else bias, aux=aux))
+            res.append(f"{t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
+        ops._L().mmae_gemm_nt_set_variant(0)
+        print(f"gemm_nt {name:10s} M={m} N={n} K={k}: t128 {res[0]} | p256 {res[1]} | p256k32 {res[2]} | p128 {res[3]} | pp256 {res[4]}")
+    if len(sys.argv) > 1 and sys.argv[1] == "nt":
+        sys.exit(0)
+    for name, m, n, k in [("dW qkv", M, 2304, 768), ("dW proj", M, 768, 768), ("dW fc1", M, 3072, 768), ("dW fc2", M, 768, 3072),
+                          ("dW dec fc1", 50176, 1024, 256), ("dW dec proj", 50176, 256, 256)]:
+        x, y = r(m, n), r(m, k)
+        out = torch.zeros(n, k, device="cuda"); cs = torch.zeros(n, device="cuda")
+        t = timeit(lambda: ops.gemm_tn(x, y, out=out, accumulate=True, colsum_out=cs, colsum_accumulate=True))
+        print(f"gemm_tn {name:10s} M={m} N={n} K={k}: {t*1e6:8.1f} us  {2*m*n*k/t/1e12:7.1f} TF")
+    for name, B, H, nq, nk, d in [("enc", 256, 12, 99, 99, 64), ("dec self", 256, 8, 196, 196, 32), ("dec cross", 256, 8, 196, 99, 32)]:
+        if nq == nk:
+            qkv = r(B * nq, 3 * H * d); q, k_, v = qkv[:, :H*d], qkv[:, H*d:2*H*d], qkv[:, 2*H*d:]
+            dqkv = torch.empty_like(qkv); dq, dk, dv = dqkv[:, :H*d], dqkv[:, H*d:2*H*d], dqkv[:, 2*H*d:]
+        else:
+            q = r(B * nq, H * d); kv = r(B * nk, 2 * H * d); k_, v = kv[:, :H*d], kv[:, H*d:]
+            dq = torch.empty_like(q); dkv = torch.empty_like(kv); dk, dv = dkv[:, :H*d], dkv[:, H*d:]
+        o, lse = ops.attn_fwd(q, k_, v, B, H, nq, nk, d, d ** -0.5)
+        do = r(B * nq, H * d)
+        t = timeit(lambda: ops.attn_fwd(q, k_, v, B, H, nq, nk, d, d ** -0.5))
+        t2 = timeit(lambda: ops.attn_bwd(q, k_, v, o, do, lse, dq, dk, dv, B, H, nq, nk, d, d ** -0.5))
+        fl = 4.0 * B * H * nq * nk * d
+        print(f"attn {name:10s}: fwd {t*1e6:7.1f} us {fl/t/1e12:6.1f} TF | bwd {t2*1e6:7.1f} us {2*fl/t2/1e12:6.1f} TF")

@@ -27,7 +27,7 @@ def _randn(*shape, seed=0, dtype=torch.bfloat16, scale=1.0):
 
 
 # ---------------------------------------------------------------------------------------------- GEMM
-@pytest.fixture(params=[1, 2, 3, 4], ids=["tile128", "persist256", "persist256k32", "persist128"])
+@pytest.fixture(params=[1, 2, 3, 4, 5], ids=["tile128", "persist256", "persist256k32", "persist128", "pingpong256"])
 def nt_variant(request, ops):
     ops._L().mmae_gemm_nt_set_variant(request.param)
     yield request.param
