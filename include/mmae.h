@@ -71,6 +71,9 @@ int mmae_unpatchify_gemm(const void* A, long lda, const void* W, int M, int N, i
  * (dW = dC^T x A).  Split over M into fp32 slabs held in `workspace`, then reduced in a fixed order
  * (bitwise reproducible).  If colsum_out != NULL it also receives (+)= the column sums of X (the bias
  * gradient), computed by the same kernel. */
+/* Kernel choice for mmae_gemm_tn: 0 = by problem size (default), 1 = 128x128 kernel, 2 = 256x256 eight-wave kernel.
+ * Process-wide; for tests and tuning.  Set it before asking for the workspace size (the split count depends on it). */
+void mmae_gemm_tn_set_variant(int variant);
 size_t mmae_gemm_tn_workspace_bytes(int M, int N, int K);
 int mmae_gemm_tn(const void* X, long ldx, const void* Y, long ldy, int M, int N, int K, float* out, int accumulate,
                  float* colsum_out, int colsum_accumulate, void* workspace, size_t workspace_bytes, mmae_stream_t stream);

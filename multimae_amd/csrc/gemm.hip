@@ -1032,6 +1032,188 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 256 (n) x 256 (k) weight-gradient kernel with the structure of gemm_nt_pp_kernel: eight waves (2 along n x 4 along k,
+// 128 x 64 outputs each), 64 reduction rows per stage, four 16-KiB slots per stage filled by LDS-DMA seven slots ahead,
+// the two wave groups one barrier apart.  Slot images are [64 m][128 columns] (256-byte rows, 16-column blocks swizzled
+// by tn_swz) read with the transposing LDS read: slot 0 / 3 = X columns {wn*128 + (0|64) + 0..63}, slot 1 / 2 = Y columns
+// {wk*64 + (0|32) + 0..31}.  One workgroup = one (tile, M-split) pair; splits are chosen so that tiles x splits fills
+// the CUs once.  The bias gradient (column sums of X) is accumulated on the vector ALU from the X fragments already in
+// registers, each wave of a k-tile-0 workgroup taking two of its eight column fragments.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(GemmTN p, int tiles_k) {
+    extern __shared__ __attribute__((aligned(16))) char tnsmem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wk = wave & 3;
+    const int tile = blockIdx.x, split = blockIdx.y;
+    const int n0 = (tile / tiles_k) * 256, k0 = (tile % tiles_k) * 256;
+    const int m_begin = split * p.rows_per_split;
+    int m_end = m_begin + p.rows_per_split; m_end = m_end < p.M ? m_end : p.M;
+    const int nst = (m_end - m_begin + 127) / 128 * 2;  // stages of 64 rows, in pairs (one per LDS buffer)
+
+    // ---- staging: wave-instruction j of this wave fills slot rows (j*8 + wave)*4 .. +3, 16 lanes per 256-byte row.
+    // N and K are multiples of 256 here, so no column needs clamping: slot 3 is slot 0 shifted by 64 columns, slot 2 is
+    // slot 1 shifted by 32, and the second instruction is the first shifted by 32 rows.
+    const int r_st = wave * 4 + (lane >> 4);
+    const bf16* xsrc[2]; const bf16* ysrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = j * 32 + r_st;
+        const int c16 = lane & 15;
+        const int col = (((c16 >> 1) ^ tn_swz(r)) << 4) + (c16 & 1) * 8;  // column of the slot image held at this lane's position
+        xsrc[j] = p.X + (long)(m_begin + r) * p.ldx + n0 + (col >> 6) * 128 + (col & 63);
+        ysrc[j] = p.Y + (long)(m_begin + r) * p.ldy + k0 + (col >> 5) * 64 + (col & 31);
+    }
+    int s_st[4] = {0, 0, 0, 0};  // next stage index per slot
+    auto stage_slot = [&](auto slot_c) {
+        constexpr int s = decltype(slot_c)::value;
+        char* dst = tnsmem + (s_st[s] & 1) * PP_KT_BYTES + s * PP_H_BYTES + wave * 1024;
+        constexpr bool is_x = (s == 0 || s == 3);
+        const long off = (long)s_st[s] * 64 * (is_x ? p.ldx : p.ldy) + (s == 3 ? 64 : (s == 2 ? 32 : 0));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = m_begin + s_st[s] * 64 + j * 32 + r_st < m_end;   // rows past the split read zeros
+            const bf16* g = (is_x ? xsrc[j] : ysrc[j]) + off;
+            glds16(ok ? (const void*)g : (const void*)g_zero_page, dst + j * 8 * 1024);
+        }
+        ++s_st[s];
+    };
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
+
+    stage_slot(S0{}); stage_slot(S1{}); stage_slot(S2{}); stage_slot(S3{});
+    stage_slot(S0{}); stage_slot(S1{}); stage_slot(S2{});
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 acc[2][4][4];  // [X half][ki][ni] : D'[k = ki*16 + g*4 + r][n = ni*16 + i16]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+    bf16x8 xf[4][2], ylo[2][2], yhi[2][2];
+    // transposing reads: rows r = ms*32 + 8g + q + 4h; tn_swz(r) = q | (g & 1) << 2 for all of them
+    const int rbase = (8 * g + q) * 256 + pp * 8, rswz = q | ((g & 1) << 2);
+    auto frag = [&](const char* slot, int nb, int ms) -> bf16x8 {
+        const char* a = slot + rbase + ((nb ^ rswz) << 5) + ms * 8192;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a + 1024));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    const bool do_colsum = p.colsum != nullptr && k0 == 0;
+    float cs[2] = {0.f, 0.f};  // column sums of X fragments ni = (wk & 1) * 2 + {0, 1} of X half (wk >> 1)
+    auto read_x = [&](const char* slot, int half) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms) xf[ni][ms] = frag(slot, wn * 4 + ni, ms);
+    };
+    auto colsum_x = [&](int half) {
+        if (do_colsum && (wk >> 1) == half) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ms = 0; ms < 2; ++ms) {
+                    const bf16x8 v = (wk & 1) ? xf[2 + t][ms] : xf[t][ms];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cs[t] += (float)v[e];
+                }
+        }
+    };
+    auto read_y = [&](const char* slot, bf16x8 (&y)[2][2]) {
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms) y[ki][ms] = frag(slot, wk * 2 + ki, ms);
+    };
+    auto mfma_quad = [&](f32x4 (&c)[4][4], int kbase, const bf16x8 (&y)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+            for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    c[kbase + ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[ki][ms], xf[ni][ms], c[kbase + ki][ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    if (wn == 1) __builtin_amdgcn_s_barrier();  // second wave group runs one barrier behind
+
+    for (int st = 0; st < nst; st += 2) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const char* buf = tnsmem + b * PP_KT_BYTES;
+            // ---- phase 0: X-lo (slot 0) and Y-lo (slot 1) ----
+            read_x(buf, 0);
+            read_y(buf + PP_H_BYTES, ylo);
+            stage_slot(S3{});
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the slot-0 reads are done before the barrier
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_quad(acc[0], 0, ylo);
+            colsum_x(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 1: Y-hi (slot 2) ----
+            read_y(buf + 2 * PP_H_BYTES, yhi);
+            stage_slot(S0{});
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_quad(acc[0], 2, yhi);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 2: X-hi (slot 3) ----
+            read_x(buf + 3 * PP_H_BYTES, 1);
+            stage_slot(S1{});
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_quad(acc[1], 2, yhi);
+            colsum_x(1);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 3 ----
+            stage_slot(S2{});
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_quad(acc[1], 0, ylo);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (wn == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    float* out = p.out + (long)split * p.slab;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 128 + h * 64 + ni * 16 + i16;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int ki = 0; ki < 4; ++ki) {
+                const int k = k0 + wk * 64 + ki * 16 + g * 4;
+                if (k >= p.K) continue;
+                *(f32x4*)(out + (long)n * p.K + k) = acc[h][ki][ni];
+            }
+        }
+    if (do_colsum) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v = cs[t];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int n = n0 + wn * 128 + (wk >> 1) * 64 + ((wk & 1) * 2 + t) * 16 + i16;
+            if (g == 0 && n < p.N) p.colsum[(long)split * p.N + n] = v;
+        }
+    }
+}
+
 // out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i]; the same for the column-sum slabs (scalar tail loop)
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab, int nsplit, float* __restrict__ out,
                                    long n4, int accumulate, const float* __restrict__ cslabs, int n_cols,
@@ -1051,7 +1233,25 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab, i
     }
 }
 
+static int g_tn_variant = 0;  // 0 = by problem size, 1 = 128x128 kernel, 2 = 256x256 ping-pong kernel
+extern "C" void mmae_gemm_tn_set_variant(int v) { g_tn_variant = v; }
+
+static bool tn_use_pp(int M, int N, int K) {
+    if (g_tn_variant == 1 || N % 256 != 0 || K % 256 != 0) return false;
+    if (g_tn_variant == 2) return true;
+    // worth a whole CU per workgroup when there are enough 256x256 tiles to share few splits and a long reduction
+    const int tiles = ((N + 255) / 256) * ((K + 255) / 256);
+    return tiles >= 12 && M >= 8192;
+}
+
 static int tn_splits(int M, int N, int K) {
+    if (tn_use_pp(M, N, K)) {
+        const int tiles = ((N + 255) / 256) * ((K + 255) / 256);
+        int s = num_cus() / tiles;  // one resident round of one workgroup per CU
+        const int max_s = (M + 1023) / 1024;
+        if (s > max_s) s = max_s;
+        return s < 1 ? 1 : s;
+    }
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     // One resident round: 256 CUs x 2 workgroups of this kernel fit at once; a grid a little over that would run a
     // second, nearly empty round (576 workgroups took as long as 1024), so split M only as far as tiles * s <= 512.
@@ -1082,16 +1282,30 @@ extern "C" int mmae_gemm_tn(const void* X, long ldx, const void* Y, long ldy, in
                  "gemm_tn: workspace %zu bytes < required %zu", workspace_bytes, need);
     GemmTN p = {};
     p.X = (const bf16*)X; p.ldx = ldx; p.Y = (const bf16*)Y; p.ldy = ldy; p.M = M; p.N = N; p.K = K;
-    int rps = (M + s - 1) / s; rps = (rps + TN_ROWS - 1) / TN_ROWS * TN_ROWS;
+    const bool pp = tn_use_pp(M, N, K);
+    const int gran = pp ? 2 * TN_ROWS : TN_ROWS;
+    int rps = (M + s - 1) / s; rps = (rps + gran - 1) / gran * gran;
     p.rows_per_split = rps;
     p.slab = (long)N * K;
     float* tmp = direct ? out : (float*)workspace;
     float* ctmp = colsum_out ? (direct ? colsum_out : (float*)workspace + (size_t)s * N * K) : nullptr;
     p.out = tmp;
     p.colsum = ctmp;
-    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, s), dim3(256), 0, stream, p);
-    MMAE_CHECK_LAUNCH("gemm_tn");
+    if (pp) {
+        static bool reserved = false;
+        if (!reserved) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_KT_BYTES);
+            MMAE_REQUIRE(e == hipSuccess, MMAE_ELAUNCH, "gemm_tn: cannot reserve LDS: %s", hipGetErrorString(e));
+            reserved = true;
+        }
+        const int tk = (K + 255) / 256, tiles = ((N + 255) / 256) * tk;
+        hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3(tiles, s), dim3(512), 2 * PP_KT_BYTES, stream, p, tk);
+        MMAE_CHECK_LAUNCH("gemm_tn_pp");
+    } else {
+        const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, s), dim3(256), 0, stream, p);
+        MMAE_CHECK_LAUNCH("gemm_tn");
+    }
     if (!direct) {
         const long n4 = (long)N * K / 4;
         int blocks = (int)((n4 + 255) / 256); blocks = blocks > 2048 ? 2048 : blocks;

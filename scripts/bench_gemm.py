@@ -39,12 +39,19 @@ if __name__ == "__main__":
         print(f"gemm_nt {name:10s} M={m} N={n} K={k}: t128 {res[0]} | p256 {res[1]} | p256k32 {res[2]} | p128 {res[3]} | pp256 {res[4]}")
     if len(sys.argv) > 1 and sys.argv[1] == "nt":
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "tn":
+        pass
     for name, m, n, k in [("dW qkv", M, 2304, 768), ("dW proj", M, 768, 768), ("dW fc1", M, 3072, 768), ("dW fc2", M, 768, 3072),
                           ("dW dec fc1", 50176, 1024, 256), ("dW dec proj", 50176, 256, 256)]:
         x, y = r(m, n), r(m, k)
         out = torch.zeros(n, k, device="cuda"); cs = torch.zeros(n, device="cuda")
-        t = timeit(lambda: ops.gemm_tn(x, y, out=out, accumulate=True, colsum_out=cs, colsum_accumulate=True))
-        print(f"gemm_tn {name:10s} M={m} N={n} K={k}: {t*1e6:8.1f} us  {2*m*n*k/t/1e12:7.1f} TF")
+        res = []
+        for variant in (1, 2):
+            ops._L().mmae_gemm_tn_set_variant(variant)
+            t = timeit(lambda: ops.gemm_tn(x, y, out=out, accumulate=True, colsum_out=cs, colsum_accumulate=True))
+            res.append(f"{t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
+        ops._L().mmae_gemm_tn_set_variant(0)
+        print(f"gemm_tn {name:10s} M={m} N={n} K={k}: t128 {res[0]} | pp256 {res[1]}")
     for name, B, H, nq, nk, d in [("enc", 256, 12, 99, 99, 64), ("dec self", 256, 8, 196, 196, 32), ("dec cross", 256, 8, 196, 99, 32)]:
         if nq == nk:
             qkv = r(B * nq, 3 * H * d); q, k_, v = qkv[:, :H*d], qkv[:, H*d:2*H*d], qkv[:, 2*H*d:]

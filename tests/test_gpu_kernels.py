@@ -86,8 +86,16 @@ def test_gemm_nt_strided_views(ops, nt_variant):
     assert outbuf[:, :512].abs().max().item() == 0
 
 
-@pytest.mark.parametrize("M,N,K", [(25344, 768, 768), (396, 2304, 768), (1000, 256, 1024), (50176, 256, 256), (200, 768, 1088), (64, 8, 8)])
-def test_gemm_tn(ops, M, N, K):
+@pytest.fixture(params=[1, 2], ids=["tile128", "pingpong256"])
+def tn_variant(request, ops):
+    ops._L().mmae_gemm_tn_set_variant(request.param)
+    yield request.param
+    ops._L().mmae_gemm_tn_set_variant(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(25344, 768, 768), (396, 2304, 768), (1000, 256, 1024), (50176, 256, 256), (200, 768, 1088), (64, 8, 8),
+                                   (25344, 2304, 768), (3000, 768, 3072), (130, 512, 256)])
+def test_gemm_tn(ops, tn_variant, M, N, K):
     x, y = _randn(M, N, seed=11), _randn(M, K, seed=12)
     out = ops.gemm_tn(x, y)
     ref = x.float().t() @ y.float()
@@ -108,6 +116,17 @@ def test_gemm_tn_asymmetric(ops):
     y = (torch.arange(M * 136, device="cuda").reshape(M, 136) % 239).to(torch.bfloat16)
     out = ops.gemm_tn(x, y)
     assert torch.equal(out, y[:128].float())
+
+
+def test_gemm_tn_pingpong_asymmetric_and_views(ops, tn_variant):
+    # X = rows of the identity: out[n] = Y[n] exactly; operands are column slices of wider buffers
+    M, N, K = 600, 512, 256
+    xb = torch.zeros(M, 1024, device="cuda", dtype=torch.bfloat16)
+    xb[:N, 256:256 + N] = torch.eye(N, device="cuda", dtype=torch.bfloat16)
+    yb = (torch.arange(M * 768, device="cuda").reshape(M, 768) % 241).to(torch.bfloat16)
+    x, y = xb[:, 256:256 + N], yb[:, 512:512 + K]
+    out, cs = ops.gemm_tn(x, y, colsum_out=True)
+    assert torch.equal(out, y[:N].float()) and torch.equal(cs, torch.ones(N, device="cuda"))
 
 
 def test_colsum(ops):
