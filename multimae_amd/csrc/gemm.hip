@@ -42,9 +42,12 @@ struct GemmNT {
 // Stores one wave's 64x64 accumulator block: (acc[2u][mi], acc[2u+1][mi]) = C[m = mw + mi*16 + fr][n = nw + 32*u + 8*fq + 0..7]
 // bias_regs (optional): the lane's 16 bias values, [8*u + e] = bias[nw + 32*u + 8*fq + e], for callers that cannot afford a
 // global load in the epilogue (an ordinary load's result makes the compiler drain every LDS-DMA in flight).
-template <int EPI>
+// FULL: the caller guarantees the 64x64 block lies inside the matrix; the stores then carry no per-lane condition, so
+// the epilogue is straight-line code (at every branch join the compiler waits for all outstanding memory operations,
+// the stores just issued included, before touching a loaded value again).
+template <int EPI, bool FULL = false, bool BREG = false>
 __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&acc)[4][4], int mw, int nw, int fr, int fq,
-                                                const float* bias_regs = nullptr) {
+                                                const float* bias_regs = nullptr, const bf16x8 (*h_regs)[2] = nullptr) {
     // Epilogue inputs (residual / saved pre-activation) are fetched for the whole 64x64 block before anything is stored:
     // a load issued after a store has to wait for that store as well (one in-order counter), which would serialise
     // sixteen memory round trips.
@@ -53,7 +56,7 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
     bf16x8 hsv[EPI == EPI_DGELU ? MB : 1][2];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-        if ((EPI == EPI_RESID || EPI == EPI_DGELU) && mi % MB == 0) {
+        if ((EPI == EPI_RESID || (EPI == EPI_DGELU && !h_regs)) && mi % MB == 0) {
 #pragma unroll
             for (int mj = 0; mj < MB; ++mj) {
                 int m = mw + (mi + mj) * 16 + fr;
@@ -73,7 +76,7 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
             }
         }
         const int m = mw + mi * 16 + fr;
-        if (m >= p.M) continue;
+        if (!FULL && m >= p.M) continue;
         long orow = m;
         const float* tab = nullptr;
         int ib = 0, inh = 0, inw = 0;
@@ -90,12 +93,12 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int n = nw + 32 * u + 8 * fq;
-            if (n >= p.N) continue;
+            if (!FULL && n >= p.N) continue;
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = acc[2 * u][mi][e]; v[4 + e] = acc[2 * u + 1][mi][e]; }
             if (EPI != EPI_DGELU && EPI != EPI_TOKENS && p.bias) {
-                if (bias_regs) {
+                if (BREG) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += bias_regs[8 * u + e];
                 } else {
@@ -112,7 +115,11 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
             } else if (EPI == EPI_GELU) {
                 bf16x8 h, g;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { h[e] = (bf16)v[e]; g[e] = (bf16)gelu_erf((float)h[e]); }
+                for (int e = 0; e < 8; e += 2) {
+                    h[e] = (bf16)v[e]; h[e + 1] = (bf16)v[e + 1];
+                    const f32x2 a = gelu_poly2((f32x2){(float)h[e], (float)h[e + 1]});
+                    g[e] = (bf16)a[0]; g[e + 1] = (bf16)a[1];
+                }
                 *(bf16x8*)((bf16*)p.out + orow * p.ldo + n) = h;
                 *(bf16x8*)((bf16*)p.out2 + orow * p.ldo + n) = g;
             } else if (EPI == EPI_RESID) {
@@ -121,10 +128,13 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
                 *(f32x4*)op = (f32x4){r0[0] + v[0], r0[1] + v[1], r0[2] + v[2], r0[3] + v[3]};
                 *(f32x4*)(op + 4) = (f32x4){r1[0] + v[4], r1[1] + v[5], r1[2] + v[6], r1[3] + v[7]};
             } else if (EPI == EPI_DGELU) {
-                const bf16x8 h = hsv[EPI == EPI_DGELU ? mi % MB : 0][u];
+                const bf16x8 h = h_regs ? h_regs[mi][u] : hsv[EPI == EPI_DGELU ? mi % MB : 0][u];
                 bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16)(v[e] * gelu_erf_grad((float)h[e]));
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2 d = gelu_grad_poly2((f32x2){(float)h[e], (float)h[e + 1]});
+                    o[e] = (bf16)(v[e] * d[0]); o[e + 1] = (bf16)(v[e + 1] * d[1]);
+                }
                 *(bf16x8*)((bf16*)p.out + orow * p.ldo + n) = o;
             } else if (EPI == EPI_F32) {
                 float* op = (float*)p.out + orow * p.ldo + n;
@@ -250,7 +260,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
         cur ^= 1;
     }
 
-    store_wave_tile<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
+    if (m0 + BM <= p.M && n0 + BN <= p.N) store_wave_tile<EPI, true>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
+    else store_wave_tile<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -384,7 +395,8 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 ? 2 : 2)) void gemm_nt_persist_k
         if (++kt == nk) {
             int m0, n0;
             tile_origin(tile, m0, n0);
-            store_wave_tile<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
+            if (m0 + TBM <= p.M && n0 + BN <= p.N) store_wave_tile<EPI, true>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
+            else store_wave_tile<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -717,8 +729,38 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
                     for (int e = 0; e < 4; ++e) { bv[8 * u + e] = b0[e]; bv[8 * u + 4 + e] = b1[e]; }
                 }
             }
-            store_wave_tile<EPI>(p, acc[0], m0 + wm * 128, n0 + wn * 64, fr, fq, bv);
-            store_wave_tile<EPI>(p, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, fr, fq, bv);
+            const bool full = m0 + 256 <= p.M && n0 + 256 <= p.N;  // workgroup-uniform
+            if constexpr (EPI == EPI_DGELU) {
+                // the saved pre-activations of the whole 128x64 block first: one wait for them (and for the loads still in
+                // flight ahead of them) instead of one per half
+                bf16x8 hs[2][4][2];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        int m = m0 + wm * 128 + h2 * 64 + mi * 16 + fr;
+                        m = m < p.M ? m : p.M - 1;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            int n = n0 + wn * 64 + 32 * u + 8 * fq;
+                            n = n < p.N ? n : p.N - 8;
+                            hs[h2][mi][u] = *(const bf16x8*)((const bf16*)p.aux + (long)m * p.ldaux + n);
+                        }
+                    }
+                if (full) {
+                    store_wave_tile<EPI, true, true>(p, acc[0], m0 + wm * 128, n0 + wn * 64, fr, fq, bv, hs[0]);
+                    store_wave_tile<EPI, true, true>(p, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, fr, fq, bv, hs[1]);
+                } else {
+                    store_wave_tile<EPI, false, true>(p, acc[0], m0 + wm * 128, n0 + wn * 64, fr, fq, bv, hs[0]);
+                    store_wave_tile<EPI, false, true>(p, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, fr, fq, bv, hs[1]);
+                }
+            } else if (full) {
+                store_wave_tile<EPI, true, true>(p, acc[0], m0 + wm * 128, n0 + wn * 64, fr, fq, bv);
+                store_wave_tile<EPI, true, true>(p, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, fr, fq, bv);
+            } else {
+                store_wave_tile<EPI, false, true>(p, acc[0], m0 + wm * 128, n0 + wn * 64, fr, fq, bv);
+                store_wave_tile<EPI, false, true>(p, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, fr, fq, bv);
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -816,7 +858,8 @@ template <int EPI>
 static int launch_nt(const GemmNT& p, hipStream_t s) {
     // Measured on MI355X at the shapes of the ViT-B step.  The 256x256 ping-pong kernel runs a k-tile in about 60 % of the
     // time the 128x128 kernels need per FLOP, but a workgroup owns a whole CU, so it pays only where the tile count
-    // fills the last round of CUs (N = 2304 / 3072 at M = 25344: 87 / 93 %; N = 768: 58 %, where it loses).  Among the
+    // fills the last round of CUs (N = 2304 / 3072 at M = 25344: 87 / 93 %, the decoder shapes at M = 50176: 77 %;
+    // N = 768 at M = 25344: 58 %, where it loses).  Among the
     // 128x128 kernels the persistent ring wins for many tiles of a short K loop (N >= 2048), the plain grid elsewhere.
     const long tiles128 = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     if (g_nt_variant == 5 && p.K % 128 == 0) return launch_nt_pp<EPI>(p, s);
@@ -826,7 +869,7 @@ static int launch_nt(const GemmNT& p, hipStream_t s) {
         const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         const long rounds = (tiles256 + num_cus() - 1) / num_cus();
         const double fill = (double)tiles256 / (double)(rounds * num_cus());
-        if ((fill >= 0.85 && p.K >= 512) || (fill >= 0.75 && p.K >= 1024)) return launch_nt_pp<EPI>(p, s);
+        if (fill >= 0.75) return launch_nt_pp<EPI>(p, s);
     }
     if (g_nt_variant == 4 || (g_nt_variant == 0 && p.N >= 2048 && tiles128 >= 4 * 2 * num_cus()))
         return launch_nt_persist<EPI, 2, 2>(p, s);
