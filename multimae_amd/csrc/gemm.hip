@@ -1097,26 +1097,26 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(GemmTN p, int tiles_
     // ---- staging: wave-instruction j of this wave fills slot rows (j*8 + wave)*4 .. +3, 16 lanes per 256-byte row.
     // N and K are multiples of 256 here, so no column needs clamping: slot 3 is slot 0 shifted by 64 columns, slot 2 is
     // slot 1 shifted by 32, and the second instruction is the first shifted by 32 rows.
+    // tn_swz(r + 32) == tn_swz(r), so both instructions hold the same image columns: one pointer per operand.
     const int r_st = wave * 4 + (lane >> 4);
-    const bf16* xsrc[2]; const bf16* ysrc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = j * 32 + r_st;
+    const bf16* xsrc; const bf16* ysrc;
+    {
         const int c16 = lane & 15;
-        const int col = (((c16 >> 1) ^ tn_swz(r)) << 4) + (c16 & 1) * 8;  // column of the slot image held at this lane's position
-        xsrc[j] = p.X + (long)(m_begin + r) * p.ldx + n0 + (col >> 6) * 128 + (col & 63);
-        ysrc[j] = p.Y + (long)(m_begin + r) * p.ldy + k0 + (col >> 5) * 64 + (col & 31);
+        const int col = (((c16 >> 1) ^ tn_swz(r_st)) << 4) + (c16 & 1) * 8;  // column of the slot image held at this lane's position
+        xsrc = p.X + (long)(m_begin + r_st) * p.ldx + n0 + (col >> 6) * 128 + (col & 63);
+        ysrc = p.Y + (long)(m_begin + r_st) * p.ldy + k0 + (col >> 5) * 64 + (col & 31);
     }
     int s_st[4] = {0, 0, 0, 0};  // next stage index per slot
     auto stage_slot = [&](auto slot_c) {
         constexpr int s = decltype(slot_c)::value;
         char* dst = tnsmem + (s_st[s] & 1) * PP_KT_BYTES + s * PP_H_BYTES + wave * 1024;
         constexpr bool is_x = (s == 0 || s == 3);
-        const long off = (long)s_st[s] * 64 * (is_x ? p.ldx : p.ldy) + (s == 3 ? 64 : (s == 2 ? 32 : 0));
+        const long ld = is_x ? p.ldx : p.ldy;
+        const long off = (long)s_st[s] * 64 * ld + (s == 3 ? 64 : (s == 2 ? 32 : 0));
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const bool ok = m_begin + s_st[s] * 64 + j * 32 + r_st < m_end;   // rows past the split read zeros
-            const bf16* g = (is_x ? xsrc[j] : ysrc[j]) + off;
+            const bf16* g = (is_x ? xsrc : ysrc) + off + j * 32 * ld;
             glds16(ok ? (const void*)g : (const void*)g_zero_page, dst + j * 8 * 1024);
         }
         ++s_st[s];
@@ -1141,19 +1141,29 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(GemmTN p, int tiles_
     bf16x8 xf[4][2], ylo[2][2], yhi[2][2];
     // transposing reads: rows r = ms*32 + 8g + q + 4h; tn_swz(r) = q | (g & 1) << 2 for all of them
     const int rbase = (8 * g + q) * 256 + pp * 8, rswz = q | ((g & 1) << 2);
-    auto frag = [&](const char* slot, int nb, int ms) -> bf16x8 {
-        const char* a = slot + rbase + ((nb ^ rswz) << 5) + ms * 8192;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a);
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a + 1024));
+    // The transposing reads go through inline asm: for the builtin the compiler orders the read after every LDS-DMA in
+    // flight (s_waitcnt vmcnt(0) in front of each group of reads), which would turn the seven-slot run-ahead into a
+    // synchronous copy.  The reads are retired by the explicit lgkmcnt waits before the MFMA clusters.
+    const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) char*)tnsmem) + rbase;
+    // lb: lbase + buffer offset, made opaque once per phase so that the (loop-invariant) read addresses are recomputed
+    // there instead of being hoisted out of the loop into two dozen extra registers
+    auto frag = [&](unsigned lb, auto off_c, int nb) -> bf16x8 {
+        constexpr int off = decltype(off_c)::value;
+        const unsigned a = lb + ((nb ^ rswz) << 5);
+        bf16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"(off));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(off + 1024));
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
     const bool do_colsum = p.colsum != nullptr && k0 == 0;
     float cs[2] = {0.f, 0.f};  // column sums of X fragments ni = (wk & 1) * 2 + {0, 1} of X half (wk >> 1)
-    auto read_x = [&](const char* slot, int half) {
+    auto read_x = [&](unsigned lb, auto slot_c) {
+        constexpr int so = decltype(slot_c)::value * PP_H_BYTES;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int ms = 0; ms < 2; ++ms) xf[ni][ms] = frag(slot, wn * 4 + ni, ms);
+        for (int ni = 0; ni < 4; ++ni) {
+            xf[ni][0] = frag(lb, std::integral_constant<int, so>{}, wn * 4 + ni);
+            xf[ni][1] = frag(lb, std::integral_constant<int, so + 8192>{}, wn * 4 + ni);
+        }
     };
     auto colsum_x = [&](int half) {
         if (do_colsum && (wk >> 1) == half) {
@@ -1167,11 +1177,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(GemmTN p, int tiles_
                 }
         }
     };
-    auto read_y = [&](const char* slot, bf16x8 (&y)[2][2]) {
+    auto read_y = [&](unsigned lb, auto slot_c, bf16x8 (&y)[2][2]) {
+        constexpr int so = decltype(slot_c)::value * PP_H_BYTES;
 #pragma unroll
-        for (int ki = 0; ki < 2; ++ki)
-#pragma unroll
-            for (int ms = 0; ms < 2; ++ms) y[ki][ms] = frag(slot, wk * 2 + ki, ms);
+        for (int ki = 0; ki < 2; ++ki) {
+            y[ki][0] = frag(lb, std::integral_constant<int, so>{}, wk * 2 + ki);
+            y[ki][1] = frag(lb, std::integral_constant<int, so + 8192>{}, wk * 2 + ki);
+        }
     };
     auto mfma_quad = [&](f32x4 (&c)[4][4], int kbase, const bf16x8 (&y)[2][2]) {
         __builtin_amdgcn_s_setprio(1);
@@ -1190,10 +1202,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(GemmTN p, int tiles_
     for (int st = 0; st < nst; st += 2) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const char* buf = tnsmem + b * PP_KT_BYTES;
+            unsigned lb = lbase + b * PP_KT_BYTES;
             // ---- phase 0: X-lo (slot 0) and Y-lo (slot 1) ----
-            read_x(buf, 0);
-            read_y(buf + PP_H_BYTES, ylo);
+            asm volatile("" : "+v"(lb));
+            read_x(lb, S0{});
+            read_y(lb, S1{}, ylo);
             stage_slot(S3{});
             asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the slot-0 reads are done before the barrier
             __builtin_amdgcn_s_barrier();
@@ -1203,7 +1216,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(GemmTN p, int tiles_
             colsum_x(0);
             __builtin_amdgcn_s_barrier();
             // ---- phase 1: Y-hi (slot 2) ----
-            read_y(buf + 2 * PP_H_BYTES, yhi);
+            asm volatile("" : "+v"(lb));
+            read_y(lb, S2{}, yhi);
             stage_slot(S0{});
             __builtin_amdgcn_s_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1211,7 +1225,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(GemmTN p, int tiles_
             mfma_quad(acc[0], 2, yhi);
             __builtin_amdgcn_s_barrier();
             // ---- phase 2: X-hi (slot 3) ----
-            read_x(buf + 3 * PP_H_BYTES, 1);
+            asm volatile("" : "+v"(lb));
+            read_x(lb, S3{});
             stage_slot(S1{});
             __builtin_amdgcn_s_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1284,7 +1299,7 @@ static bool tn_use_pp(int M, int N, int K) {
     if (g_tn_variant == 2) return true;
     // worth a whole CU per workgroup when there are enough 256x256 tiles to share few splits and a long reduction
     const int tiles = ((N + 255) / 256) * ((K + 255) / 256);
-    return tiles >= 12 && M >= 8192;
+    return tiles >= 9 && M >= 8192;
 }
 
 static int tn_splits(int M, int N, int K) {
