@@ -101,11 +101,20 @@ def main():
     ips = world * B * args.steps / elapsed
 
     roof = None
-    if not args.no_roofline and rank == 0:
-        ops.PROFILE = []
+    if not args.no_roofline:
+        # Two more steps with a HIP-event pair around every GEMM / attention launch (on the stream it is launched on).
+        # Every rank runs them (the step holds collectives); rank 0 records.  The weight-gradient stream is switched off
+        # here so that a kernel's duration is its own, not that of two kernels sharing the chip.
+        from multimae_amd import functional as Fn
+        side = Fn.SIDE_STREAM_DW
+        Fn.SIDE_STREAM_DW = False
+        if rank == 0:
+            ops.PROFILE = []
         for _ in range(2):
             step(batch)
-        torch.cuda.synchronize()
+        sync()
+        Fn.SIDE_STREAM_DW = side
+    if roof is None and not args.no_roofline and rank == 0:
         fam = {}
         for name, flops, e0, e1 in ops.PROFILE:
             d = fam.setdefault(name, [0.0, 0.0, 0])
@@ -118,8 +127,6 @@ def main():
                 "avg_launch_us": round(sec / n * 1e6, 1),
                 "families": {k_: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / 2 * 1e3, 3),
                                   "launches_per_step": v[2] // 2} for k_, v in fam.items()}}
-    elif world > 1:
-        pass
 
     if rank == 0:
         out = {

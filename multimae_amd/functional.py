@@ -5,6 +5,7 @@ stream, LayerNorm statistics, softmax and the losses are fp32; every matrix prod
 accumulates in fp32.  Each function saves exactly what its backward kernels read."""
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
 import weakref
 
 import torch
@@ -86,12 +87,48 @@ def _ready(p):
         cb()
 
 
+# Weight gradients that accumulate straight into flat storage do not feed the rest of backward, so they run on a second
+# stream: their workgroups fill the CUs that the main chain's kernels leave idle in their last, partly filled round.
+SIDE_STREAM_DW = os.environ.get("MMAE_SIDE_STREAM", "1") != "0"
+_SIDE = {}  # device index -> [stream, work pending since the last join]
+
+
+def _side(device):
+    ent = _SIDE.get(device.index)
+    if ent is None:
+        ent = _SIDE[device.index] = [torch.cuda.Stream(device=device), False]
+    return ent
+
+
+def join_side_stream(device=None):
+    """Make the current stream wait for the weight-gradient stream (call before gradients are read)."""
+    for idx, ent in _SIDE.items():
+        if ent[1] and (device is None or torch.device(device).index in (None, idx)):
+            torch.cuda.current_stream(idx).wait_stream(ent[0])
+            ent[1] = False
+
+
+def side_stream_pending(device) -> Optional[torch.cuda.Stream]:
+    ent = _SIDE.get(torch.device(device).index)
+    return ent[0] if ent is not None and ent[1] else None
+
+
 def _lin_grads(dy_b: torch.Tensor, x_b: torch.Tensor, w=None, b=None):
     """(dW [N,K] f32, db [N] f32) of y = x W^T + b from bf16 dy [M,N] and x [M,K]; (None, None) when they were
     accumulated straight into w.grad / b.grad."""
     want_b = b is not None and b.requires_grad
     if _direct(w) and (not want_b or _direct(b)):
-        ops.gemm_tn(dy_b, x_b, out=w.grad, accumulate=True, colsum_out=b.grad if want_b else None, colsum_accumulate=True)
+        if SIDE_STREAM_DW:
+            ent = _side(dy_b.device)
+            side = ent[0]
+            side.wait_stream(torch.cuda.current_stream(dy_b.device))
+            with torch.cuda.stream(side):
+                ops.gemm_tn(dy_b, x_b, out=w.grad, accumulate=True, colsum_out=b.grad if want_b else None, colsum_accumulate=True)
+            dy_b.record_stream(side)
+            x_b.record_stream(side)
+            ent[1] = True
+        else:
+            ops.gemm_tn(dy_b, x_b, out=w.grad, accumulate=True, colsum_out=b.grad if want_b else None, colsum_accumulate=True)
         _ready(w)
         if want_b:
             _ready(b)

@@ -69,8 +69,8 @@ _WS = {}
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch buffer per device; every kernel that uses it runs on the current stream."""
-    key = torch.device(device).index
+    """Grow-only scratch buffer per (device, stream): kernels on one stream run in order, so they can share it."""
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

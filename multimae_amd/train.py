@@ -116,6 +116,7 @@ class FlatParams:
                                       p._version, self.sync_bf16)
 
     def zero_grad(self):
+        Fn.join_side_stream(self.grads.device)
         self.grads.zero_()
         for (_, p), o in zip(self.named, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * o:
@@ -155,9 +156,21 @@ class GradBuckets:
             b = self.bucket_of[i]
             self.pending[b] -= 1
             if self.pending[b] == 0:
-                s, e, _ = self.buckets[b]
-                self.works.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._launch(b)
         return hook
+
+    def _launch(self, b):
+        """All-reduce bucket b once every kernel that writes it has been enqueued: on the current stream, or on the
+        weight-gradient stream (functional._lin_grads).  The collective is issued from a stream that waits for both."""
+        s, e, _ = self.buckets[b]
+        buf = self.flat.grads[s:e]
+        side = Fn.side_stream_pending(buf.device) if buf.is_cuda else None
+        if side is None:
+            self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        side.wait_stream(torch.cuda.current_stream(buf.device))
+        with torch.cuda.stream(side):
+            self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Call after backward: launches any bucket whose parameters received no gradient, waits for all."""
@@ -165,8 +178,7 @@ class GradBuckets:
             return
         for b, left in enumerate(self.pending):
             if left > 0:
-                s, e, _ = self.buckets[b]
-                self.works.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._launch(b)
         for w in self.works:
             w.wait()
         self.works = []
@@ -216,6 +228,7 @@ class FlatAdamW:
         With skip_grad the number of applied updates lives on the device (no host synchronisation)."""
         if self.param_groups[1]["lr"] != self.param_groups[0]["lr"]:
             raise ValueError("FlatAdamW applies one learning rate to both parameter groups")
+        Fn.join_side_stream(self.flat.grads.device)
         self.step_count += 1
         if (clip_grad or skip_grad) and grad_sumsq is None:
             grad_sumsq = self.grad_norm_sq()
@@ -229,6 +242,7 @@ class FlatAdamW:
         Fn.bump_weight_epoch()
 
     def grad_norm_sq(self) -> torch.Tensor:
+        Fn.join_side_stream(self.flat.grads.device)
         return ops.sumsq(self.flat.grads)
 
     def state_dict(self):
@@ -297,6 +311,7 @@ class PretrainStep:
         loss = sum(task_losses.values())
         loss.backward()
         self.buckets.finish()
+        Fn.join_side_stream()
         gn2 = self.opt.grad_norm_sq()  # of the summed (not yet averaged) gradients: norm = sqrt(gn2) / world
         self.opt.step(grad_scale=1.0 / self.world, clip_grad=self.clip_grad, skip_grad=self.skip_grad, grad_sumsq=gn2)
         return loss.detach(), task_losses, gn2
