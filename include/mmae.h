@@ -86,13 +86,17 @@ int mmae_colsum_bf16(const void* X, long ldx, int M, int N, float* out, int accu
 /* ---- LayerNorm (eps 1e-6; multimae/multimae_utils.py:283-284, output_adapters.py:350-353) ---------
  * fwd: y(bf16) = LN(x(f32)) * gamma + beta; saves mean and rstd per row.
  * bwd: dx(f32) = (dres ? dres : 0) + LN'(dy(bf16)); optional bf16 copy of dx; dgamma/dbeta are
- *      written as per-block partial rows into `workspace` and summed by a second kernel. */
+ *      written as per-block partial rows into `workspace` and summed by a second kernel.  With dgamma = dbeta = NULL
+ *      the partial rows stay in `workspace` for a later mmae_layernorm_param_reduce (e.g. on another stream). */
 int mmae_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean, float* rstd,
                        int rows, int dim, float eps, mmae_stream_t stream);
 size_t mmae_layernorm_bwd_workspace_bytes(int rows, int dim);
 int mmae_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
                        const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta, int accumulate,
                        int rows, int dim, void* workspace, size_t workspace_bytes, mmae_stream_t stream);
+
+int mmae_layernorm_param_reduce(const void* workspace, size_t workspace_bytes, int rows, int dim, float* dgamma, float* dbeta,
+                                int accumulate, mmae_stream_t stream);
 
 /* ---- attention (multimae/multimae_utils.py:200-204 and :240-244) ----------------------------
  * softmax(q k^T * scale) v per (batch, head) without materialising the scores.  q/k/v/o rows are

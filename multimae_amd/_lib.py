@@ -25,6 +25,7 @@ SIGNATURES = {
     "mmae_colsum_bf16": (_i, [_p, _l, _i, _i, _p, _i, _p, _z, _p]),
     "mmae_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "mmae_layernorm_bwd_workspace_bytes": (_z, [_i, _i]),
+    "mmae_layernorm_param_reduce": (_i, [_p, _z, _i, _i, _p, _p, _i, _p]),
     "mmae_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "mmae_attn_fwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _f, _p]),
     "mmae_attn_bwd_workspace_bytes": (_z, [_i, _i, _i]),

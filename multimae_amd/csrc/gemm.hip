@@ -7,6 +7,7 @@
 // 16-byte global->LDS DMA into a double-buffered, XOR-swizzled LDS image.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -869,7 +870,12 @@ static int launch_nt(const GemmNT& p, hipStream_t s) {
         const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         const long rounds = (tiles256 + num_cus() - 1) / num_cus();
         const double fill = (double)tiles256 / (double)(rounds * num_cus());
-        if (fill >= 0.75) return launch_nt_pp<EPI>(p, s);
+        static double min_fill = -1.0;
+        if (min_fill < 0.0) {
+            const char* e = getenv("MMAE_PP_FILL");
+            min_fill = e ? atof(e) : 0.75;
+        }
+        if (fill >= min_fill) return launch_nt_pp<EPI>(p, s);
     }
     if (g_nt_variant == 4 || (g_nt_variant == 0 && p.N >= 2048 && tiles128 >= 4 * 2 * num_cus()))
         return launch_nt_persist<EPI, 2, 2>(p, s);

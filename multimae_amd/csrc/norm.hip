@@ -167,7 +167,8 @@ extern "C" size_t mmae_layernorm_bwd_workspace_bytes(int rows, int dim) {
 extern "C" int mmae_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                   const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta, int accumulate,
                                   int rows, int dim, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    MMAE_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, MMAE_EINVAL, "layernorm_bwd: null pointer");
+    MMAE_REQUIRE(dy && x && gamma && mean && rstd && dx && workspace, MMAE_EINVAL, "layernorm_bwd: null pointer");
+    MMAE_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), MMAE_EINVAL, "layernorm_bwd: give both parameter gradients or neither");
     MMAE_REQUIRE(rows > 0 && dim > 0 && dim % 4 == 0 && dim <= 256 * LN_MAXV, MMAE_ESHAPE,
                  "layernorm_bwd: dim=%d must be a multiple of 4 and <= %d", dim, 256 * LN_MAXV);
     MMAE_REQUIRE(workspace_bytes >= mmae_layernorm_bwd_workspace_bytes(rows, dim), MMAE_EWORKSPACE, "layernorm_bwd: workspace too small");
@@ -175,8 +176,17 @@ extern "C" int mmae_layernorm_bwd(const void* dy, const float* x, const float* g
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const bf16*)dy, x, gamma, mean, rstd, dres, dx,
                        (bf16*)dx_bf16, (float*)workspace, rows, dim);
     MMAE_CHECK_LAUNCH("layernorm_bwd");
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * dim + 31) / 32), dim3(1024), 0, stream, (const float*)workspace, nb, dim,
-                       dgamma, dbeta, accumulate);
+    if (dgamma) return mmae_layernorm_param_reduce(workspace, workspace_bytes, rows, dim, dgamma, dbeta, accumulate, stream);
+    return MMAE_OK;
+}
+
+extern "C" int mmae_layernorm_param_reduce(const void* workspace, size_t workspace_bytes, int rows, int dim, float* dgamma,
+                                           float* dbeta, int accumulate, hipStream_t stream) {
+    MMAE_REQUIRE(workspace && dgamma && dbeta, MMAE_EINVAL, "layernorm_param_reduce: null pointer");
+    MMAE_REQUIRE(rows > 0 && dim > 0 && workspace_bytes >= mmae_layernorm_bwd_workspace_bytes(rows, dim), MMAE_EWORKSPACE,
+                 "layernorm_param_reduce: workspace too small");
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * dim + 31) / 32), dim3(1024), 0, stream, (const float*)workspace,
+                       ln_bwd_blocks(rows), dim, dgamma, dbeta, accumulate);
     MMAE_CHECK_LAUNCH("ln_param_reduce");
     return MMAE_OK;
 }

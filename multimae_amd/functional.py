@@ -141,7 +141,18 @@ def _lin_grads(dy_b: torch.Tensor, x_b: torch.Tensor, w=None, b=None):
 def _ln_bwd(dy, x, n_w, n_b, mean, rstd, dres=None, shadow=False):
     """LayerNorm backward; (dx, dgamma, dbeta) with the parameter gradients None when written in place."""
     if _direct(n_w) and _direct(n_b):
-        dx, dxb, _, _ = ops.layernorm_bwd(dy, x, n_w, mean, rstd, dres=dres, want_bf16=shadow, dgamma=n_w.grad, dbeta=n_b.grad)
+        if SIDE_STREAM_DW:
+            # the parameter-gradient reduction (a few dozen workgroups) leaves the main chain: it would queue behind the
+            # weight-gradient workgroups that own the CUs
+            dx, dxb, part, _ = ops.layernorm_bwd(dy, x, n_w, mean, rstd, dres=dres, want_bf16=shadow, defer_params=True)
+            ent = _side(x.device)
+            ent[0].wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(ent[0]):
+                ops.layernorm_param_reduce(part, x.numel() // x.shape[-1], x.shape[-1], n_w.grad, n_b.grad, True)
+            part.record_stream(ent[0])
+            ent[1] = True
+        else:
+            dx, dxb, _, _ = ops.layernorm_bwd(dy, x, n_w, mean, rstd, dres=dres, want_bf16=shadow, dgamma=n_w.grad, dbeta=n_b.grad)
         _ready(n_w)
         _ready(n_b)
         dg = db = None

@@ -165,8 +165,10 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
 
 
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
-                  dres: Optional[torch.Tensor] = None, want_bf16: bool = False, dgamma=None, dbeta=None):
-    """Returns (dx f32 [= dres + LN'(dy)], dx bf16 or None, dgamma, dbeta); given dgamma / dbeta are accumulated into."""
+                  dres: Optional[torch.Tensor] = None, want_bf16: bool = False, dgamma=None, dbeta=None, defer_params: bool = False):
+    """Returns (dx f32 [= dres + LN'(dy)], dx bf16 or None, dgamma, dbeta); given dgamma / dbeta are accumulated into.
+    defer_params: leave the parameter gradients as per-block partial rows in a buffer of their own, returned in place of
+    dgamma (finish with layernorm_param_reduce, possibly on another stream); dbeta is then None."""
     _req(dy, BF16, "layernorm_bwd dy"); _req(x, F32, "layernorm_bwd x")
     dim = x.shape[-1]
     rows = x.numel() // dim
@@ -174,14 +176,27 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
         _req(dres, F32, "layernorm_bwd dres")
     dx = torch.empty(x.shape, dtype=F32, device=x.device)
     dxb = torch.empty(x.shape, dtype=BF16, device=x.device) if want_bf16 else None
+    nbytes = _L().mmae_layernorm_bwd_workspace_bytes(rows, dim)
+    if defer_params:
+        part = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        _lib.check(_L().mmae_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(dxb),
+                                           None, None, 0, rows, dim, _ptr(part), part.numel(), _stream()), "layernorm_bwd")
+        return dx, dxb, part, None
     acc = int(dgamma is not None)
     if dgamma is None:
         dgamma = torch.empty((dim,), dtype=F32, device=x.device)
         dbeta = torch.empty((dim,), dtype=F32, device=x.device)
-    ws = workspace(_L().mmae_layernorm_bwd_workspace_bytes(rows, dim), x.device)
+    ws = workspace(nbytes, x.device)
     _lib.check(_L().mmae_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(dxb),
                                        _ptr(dgamma), _ptr(dbeta), acc, rows, dim, _ptr(ws), ws.numel(), _stream()), "layernorm_bwd")
     return dx, dxb, dgamma, dbeta
+
+
+def layernorm_param_reduce(part: torch.Tensor, rows: int, dim: int, dgamma: torch.Tensor, dbeta: torch.Tensor, accumulate: bool):
+    """Sum the per-block partial rows left by layernorm_bwd(defer_params=True) into dgamma / dbeta (on the current stream)."""
+    _req(dgamma, F32, "layernorm_param_reduce dgamma"); _req(dbeta, F32, "layernorm_param_reduce dbeta")
+    _lib.check(_L().mmae_layernorm_param_reduce(_ptr(part), part.numel(), rows, dim, _ptr(dgamma), _ptr(dbeta), int(accumulate),
+                                                _stream()), "layernorm_param_reduce")
 
 
 # --------------------------------------------------------------------------------------------- attention
