@@ -143,6 +143,7 @@ class GradBuckets:
             cur[2] += 1
             self.bucket_of[i] = len(self.buckets) - 1
         self.pending = [b[2] for b in self.buckets]
+        self.signalled = [False] * len(flat.named)
         self.works = []
         self.enabled = self.world > 1
         if self.enabled:
@@ -153,6 +154,11 @@ class GradBuckets:
 
     def _make_hook(self, i):
         def hook(_p):
+            # A parameter signals once per step.  Autograd also runs the post-accumulate hook of a parameter whose
+            # gradient a kernel wrote in place (the Function returned None for it), after the kernel's own signal.
+            if self.signalled[i]:
+                return
+            self.signalled[i] = True
             b = self.bucket_of[i]
             self.pending[b] -= 1
             if self.pending[b] == 0:
@@ -183,6 +189,7 @@ class GradBuckets:
             w.wait()
         self.works = []
         self.pending = [b[2] for b in self.buckets]
+        self.signalled = [False] * len(self.signalled)
 
 
 class FlatAdamW:

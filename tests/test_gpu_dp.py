@@ -1,0 +1,62 @@
+"""Data-parallel step on the GPU with two ranks sharing cuda:0 (gloo collectives over device tensors): exercises the
+bucket hooks fired by the kernels' in-place gradients, the weight-gradient stream and the 1/world scaling.  (RCCL does not
+accept two ranks on one device; the collective backend is the only difference from the multi-GPU run.)"""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    from tests.test_gpu_model import _build, _losses
+    from multimae_amd.train import PretrainStep
+    cfg = O.small_cfg()
+    model = _build(cfg)
+    model.load_state_dict(G.perturbed_state(cfg, seed=7))
+    model.cuda()
+    step = PretrainStep(model, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05, bucket_mb=0.25, clip_grad=0.5)
+    assert step.world == 2 and step.buckets.enabled and len(step.buckets.buckets) > 3
+    x = {d: t.cuda() for d, t in G.seeded_inputs(cfg, B=4, seed=3).items()}        # the same batch on both ranks
+    rnd = O.draw_mask_randomness(4, [16, 16], 1.0, torch.Generator().manual_seed(2))
+    for _ in range(2):
+        loss, _, gn2 = step(x, mask_randomness=rnd)
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({"params": step.flat.params.cpu(), "gn2": gn2.cpu(), "loss": loss.cpu()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_rank_on_identical_batches(tmp_path):
+    """Both ranks see the same batch and masks, so the averaged gradient is the single-rank gradient: (g + g) / 2 == g
+    exactly, and two optimizer steps must land on bitwise identical parameters."""
+    out = str(tmp_path / "dp.pt")
+    port = 29700 + os.getpid() % 200
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    from tests.test_gpu_model import _build, _losses
+    from multimae_amd.train import PretrainStep
+    cfg = O.small_cfg()
+    model = _build(cfg)
+    model.load_state_dict(G.perturbed_state(cfg, seed=7))
+    model.cuda()
+    step = PretrainStep(model, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05, clip_grad=0.5)
+    x = {d: t.cuda() for d, t in G.seeded_inputs(cfg, B=4, seed=3).items()}
+    rnd = O.draw_mask_randomness(4, [16, 16], 1.0, torch.Generator().manual_seed(2))
+    for _ in range(2):
+        loss, _, gn2 = step(x, mask_randomness=rnd)
+    assert torch.equal(got["loss"], loss.cpu())
+    assert torch.equal(got["gn2"], 4 * gn2.cpu())            # norm of the summed gradients: |2g|^2
+    assert torch.equal(got["params"], step.flat.params.cpu())
