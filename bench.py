@@ -115,17 +115,23 @@ def main():
         sync()
         Fn.SIDE_STREAM_DW = side
     if roof is None and not args.no_roofline and rank == 0:
-        fam = {}
-        for name, flops, e0, e1 in ops.PROFILE:
-            d = fam.setdefault(name, [0.0, 0.0, 0])
-            d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
+        fam, ker = {}, {}
+        for name, flops, e0, e1, label in ops.PROFILE:
+            dt = e0.elapsed_time(e1) * 1e-3
+            for table, key in ((fam, name), (ker, label)):
+                d = table.setdefault(key, [0.0, 0.0, 0])
+                d[0] += flops; d[1] += dt; d[2] += 1
         ops.PROFILE = None
-        name, (fl, sec, n) = max(fam.items(), key=lambda kv: kv[1][1])
+        # the dominant kernel = the single kernel (name as rocprofv3 prints it) with the most time per step
+        name, (fl, sec, n) = max(((k_, v) for k_, v in ker.items() if v[0] > 0), key=lambda kv: kv[1][1])
         ach = fl / sec / 1e12
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": n // 2,
                 "avg_launch_us": round(sec / n * 1e6, 1),
-                "families": {k_: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / 2 * 1e3, 3),
+                "kernels": {k_: {"tflops": round(v[0] / v[1] / 1e12, 1) if v[0] > 0 else None, "ms_per_step": round(v[1] / 2 * 1e3, 3),
+                                 "launches_per_step": v[2] // 2, "avg_launch_us": round(v[1] / v[2] * 1e6, 1)}
+                            for k_, v in sorted(ker.items(), key=lambda kv: -kv[1][1])[:8]},
+                "families": {k_: {"tflops": round(v[0] / v[1] / 1e12, 1) if v[0] > 0 else None, "ms_per_step": round(v[1] / 2 * 1e3, 3),
                                   "launches_per_step": v[2] // 2} for k_, v in fam.items()}}
 
     if rank == 0:

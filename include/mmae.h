@@ -54,6 +54,8 @@ int mmae_gemm_nt(int epi, const void* A, long lda, const void* W, long ldw, int 
  * 4 = persistent 128x128 (2-stage ring), 5 = 256x256 eight-wave ping-pong kernel (K a multiple of 128, else as 0).
  * Process-wide; for tests and tuning. */
 void mmae_gemm_nt_set_variant(int variant);
+/* Kernel used by the calling thread's last mmae_gemm_nt / patch-embed / un-patchify call (codes as above, never 0). */
+int mmae_gemm_nt_last_kernel(void);
 
 /* Patch projection of the kept tokens only: out[(m/seg_in)*seg_out + m%seg_in] = A[m] x W^T + add_tab[add_idx[m]]
  * where A holds the packed patches (mmae_pack_patches), W the per-domain Conv2d weights concatenated along K
@@ -74,6 +76,10 @@ int mmae_unpatchify_gemm(const void* A, long lda, const void* W, int M, int N, i
 /* Kernel choice for mmae_gemm_tn: 0 = by problem size (default), 1 = 128x128 kernel, 2 = 256x256 eight-wave kernel.
  * Process-wide; for tests and tuning.  Set it before asking for the workspace size (the split count depends on it). */
 void mmae_gemm_tn_set_variant(int variant);
+int mmae_gemm_tn_last_kernel(void);
+/* For timing the two launches of mmae_gemm_tn separately: the calling thread's next calls run 1 = the split GEMM only
+ * (slabs stay in the workspace), 2 = the slab reduction only (same arguments), 0 = both (default). */
+void mmae_gemm_tn_set_phase(int phase);
 size_t mmae_gemm_tn_workspace_bytes(int M, int N, int K);
 int mmae_gemm_tn(const void* X, long ldx, const void* Y, long ldy, int M, int N, int K, float* out, int accumulate,
                  float* colsum_out, int colsum_accumulate, void* workspace, size_t workspace_bytes, mmae_stream_t stream);

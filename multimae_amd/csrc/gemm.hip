@@ -852,6 +852,12 @@ static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
     return MMAE_OK;
 }
 
+static thread_local int g_tn_phase = 0;  // 0 = split GEMM and slab reduction, 1 = GEMM only, 2 = reduction only
+extern "C" void mmae_gemm_tn_set_phase(int phase) { g_tn_phase = phase; }
+static thread_local int g_last_nt = 0, g_last_tn = 0;  // kernel chosen by this thread's last call (same codes as *_set_variant)
+extern "C" int mmae_gemm_nt_last_kernel(void) { return g_last_nt; }
+extern "C" int mmae_gemm_tn_last_kernel(void) { return g_last_tn; }
+
 static int g_nt_variant = 0;  // 0 = choose by size, 1 = always 128x128, 2 = always persistent 256x128
 extern "C" void mmae_gemm_nt_set_variant(int v) { g_nt_variant = v; }
 
@@ -863,9 +869,9 @@ static int launch_nt(const GemmNT& p, hipStream_t s) {
     // N = 768 at M = 25344: 58 %, where it loses).  Among the
     // 128x128 kernels the persistent ring wins for many tiles of a short K loop (N >= 2048), the plain grid elsewhere.
     const long tiles128 = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    if (g_nt_variant == 5 && p.K % 128 == 0) return launch_nt_pp<EPI>(p, s);
-    if (g_nt_variant == 2) return launch_nt_persist<EPI, 4, 3>(p, s);
-    if (g_nt_variant == 3) return launch_nt_persist32<EPI>(p, s);
+    if (g_nt_variant == 5 && p.K % 128 == 0) { g_last_nt = 5; return launch_nt_pp<EPI>(p, s); }
+    if (g_nt_variant == 2) { g_last_nt = 2; return launch_nt_persist<EPI, 4, 3>(p, s); }
+    if (g_nt_variant == 3) { g_last_nt = 3; return launch_nt_persist32<EPI>(p, s); }
     if (g_nt_variant == 0 && p.K % 128 == 0 && EPI != EPI_RESID && EPI != EPI_TOKENS && EPI != EPI_UNPATCH) {
         const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         const long rounds = (tiles256 + num_cus() - 1) / num_cus();
@@ -875,10 +881,13 @@ static int launch_nt(const GemmNT& p, hipStream_t s) {
             const char* e = getenv("MMAE_PP_FILL");
             min_fill = e ? atof(e) : 0.75;
         }
-        if (fill >= min_fill) return launch_nt_pp<EPI>(p, s);
+        if (fill >= min_fill) { g_last_nt = 5; return launch_nt_pp<EPI>(p, s); }
     }
-    if (g_nt_variant == 4 || (g_nt_variant == 0 && p.N >= 2048 && tiles128 >= 4 * 2 * num_cus()))
+    if (g_nt_variant == 4 || (g_nt_variant == 0 && p.N >= 2048 && tiles128 >= 4 * 2 * num_cus())) {
+        g_last_nt = 4;
         return launch_nt_persist<EPI, 2, 2>(p, s);
+    }
+    g_last_nt = 1;
     const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(tm * tn), dim3(256), 0, s, p);
     MMAE_CHECK_LAUNCH("gemm_nt");
@@ -1347,6 +1356,7 @@ extern "C" int mmae_gemm_tn(const void* X, long ldx, const void* Y, long ldy, in
     GemmTN p = {};
     p.X = (const bf16*)X; p.ldx = ldx; p.Y = (const bf16*)Y; p.ldy = ldy; p.M = M; p.N = N; p.K = K;
     const bool pp = tn_use_pp(M, N, K);
+    g_last_tn = pp ? 2 : 1;
     const int gran = pp ? 2 * TN_ROWS : TN_ROWS;
     int rps = (M + s - 1) / s; rps = (rps + gran - 1) / gran * gran;
     p.rows_per_split = rps;
@@ -1355,7 +1365,9 @@ extern "C" int mmae_gemm_tn(const void* X, long ldx, const void* Y, long ldy, in
     float* ctmp = colsum_out ? (direct ? colsum_out : (float*)workspace + (size_t)s * N * K) : nullptr;
     p.out = tmp;
     p.colsum = ctmp;
-    if (pp) {
+    if (g_tn_phase == 2) {
+        // reduction only: the slabs are already in the workspace
+    } else if (pp) {
         static bool reserved = false;
         if (!reserved) {
             hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_KT_BYTES);
@@ -1370,7 +1382,7 @@ extern "C" int mmae_gemm_tn(const void* X, long ldx, const void* Y, long ldy, in
         hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, s), dim3(256), 0, stream, p);
         MMAE_CHECK_LAUNCH("gemm_tn");
     }
-    if (!direct) {
+    if (!direct && g_tn_phase != 1) {
         const long n4 = (long)N * K / 4;
         int blocks = (int)((n4 + 255) / 256); blocks = blocks > 2048 ? 2048 : blocks;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, tmp, p.slab, s, out, n4, accumulate,

@@ -47,9 +47,20 @@ def _rows2d(t: torch.Tensor, name: str):
 PROFILE = None
 
 
+_NT_KERNELS = {1: "gemm_nt_kernel<%d>", 2: "gemm_nt_persist_kernel<%d, 4, 3>", 3: "gemm_nt_persist32_kernel<%d>",
+               4: "gemm_nt_persist_kernel<%d, 2, 2>", 5: "gemm_nt_pp_kernel<%d>"}
+_TN_KERNELS = {1: "gemm_tn_kernel", 2: "gemm_tn_pp_kernel"}
+
+
+def _nt_label(epi):
+    return _NT_KERNELS.get(_L().mmae_gemm_nt_last_kernel(), "gemm_nt?<%d>") % epi
+
+
 class _Timed:
-    def __init__(self, name, flops):
-        self.name, self.flops = name, flops
+    """HIP-event pair around one launch when PROFILE is a list: (family, flops, start, end, kernel name as rocprof prints it)."""
+
+    def __init__(self, name, flops, label=None):
+        self.name, self.flops, self.label = name, flops, label
 
     def __enter__(self):
         if PROFILE is not None:
@@ -61,7 +72,7 @@ class _Timed:
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.name, self.flops, self.e0, self.e1))
+            PROFILE.append((self.name, self.flops, self.e0, self.e1, self.label() if callable(self.label) else (self.label or self.name)))
         return False
 
 
@@ -101,7 +112,7 @@ def gemm_nt(epi: int, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Ten
         _, _, ldaux = _rows2d(aux, "gemm_nt aux")
     if bias is not None:
         _req(bias, F32, "gemm_nt bias")
-    with _Timed("gemm_nt", 2.0 * M * N * K):
+    with _Timed("gemm_nt", 2.0 * M * N * K, lambda: _nt_label(epi)):
         _lib.check(_L().mmae_gemm_nt(epi, _ptr(a), lda, _ptr(w), ldw, M, N, K, _ptr(bias), _ptr(out), ldo, _ptr(out2),
                                      _ptr(aux), ldaux, _stream()), "gemm_nt")
     return (out, out2) if epi == EPI_GELU else out
@@ -134,9 +145,19 @@ def gemm_tn(x: torch.Tensor, y: torch.Tensor, out: Optional[torch.Tensor] = None
             raise _lib.MmaeError(f"gemm_tn: colsum_out has {cs.numel()} elements, expected {N}")
     nbytes = _L().mmae_gemm_tn_workspace_bytes(M, N, K)
     ws = workspace(nbytes, x.device)
-    with _Timed("gemm_tn", 2.0 * M * N * K):
-        _lib.check(_L().mmae_gemm_tn(_ptr(x), ldx, _ptr(y), ldy, M, N, K, _ptr(out), int(accumulate), _ptr(cs),
-                                     int(colsum_accumulate), _ptr(ws), ws.numel(), _stream()), "gemm_tn")
+    args = (_ptr(x), ldx, _ptr(y), ldy, M, N, K, _ptr(out), int(accumulate), _ptr(cs), int(colsum_accumulate), _ptr(ws), ws.numel())
+    if PROFILE is None:
+        _lib.check(_L().mmae_gemm_tn(*args, _stream()), "gemm_tn")
+    else:  # time the split GEMM and the slab reduction as the two kernels they are
+        try:
+            _L().mmae_gemm_tn_set_phase(1)
+            with _Timed("gemm_tn", 2.0 * M * N * K, lambda: _TN_KERNELS.get(_L().mmae_gemm_tn_last_kernel(), "gemm_tn?")):
+                _lib.check(_L().mmae_gemm_tn(*args, _stream()), "gemm_tn")
+            _L().mmae_gemm_tn_set_phase(2)
+            with _Timed("slab_reduce", 0.0, "slab_reduce_kernel"):
+                _lib.check(_L().mmae_gemm_tn(*args, _stream()), "gemm_tn")
+        finally:
+            _L().mmae_gemm_tn_set_phase(0)
     return out if cs is None else (out, cs)
 
 
@@ -317,7 +338,7 @@ def patch_embed_gemm(a: torch.Tensor, wcat: torch.Tensor, add_idx: torch.Tensor,
                      seg_out: int, out: torch.Tensor):
     M, K = a.shape
     N = wcat.shape[0]
-    with _Timed("gemm_nt", 2.0 * M * N * K):
+    with _Timed("gemm_nt", 2.0 * M * N * K, lambda: _nt_label(5)):
         _lib.check(_L().mmae_patch_embed_gemm(_ptr(a), _ptr(wcat), M, N, K, _ptr(add_idx), _ptr(add_tab), seg_in, seg_out,
                                               _ptr(out), out.shape[-1], _stream()), "patch_embed_gemm")
     return out
@@ -380,7 +401,7 @@ def unpatchify_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int
     M, K, lda = _rows2d(a, "unpatchify a")
     N = w.shape[0]
     img = torch.empty((B, C_, NH * P, NW * P), dtype=F32 if out_f32 else BF16, device=a.device)
-    with _Timed("gemm_nt", 2.0 * M * N * K):
+    with _Timed("gemm_nt", 2.0 * M * N * K, lambda: _nt_label(6)):
         _lib.check(_L().mmae_unpatchify_gemm(_ptr(a), lda, _ptr(w), M, N, K, _ptr(bias), _ptr(img), int(out_f32), C_, P, NH, NW,
                                              _stream()), "unpatchify_gemm")
     return img
