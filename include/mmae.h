@@ -109,8 +109,9 @@ int mmae_layernorm_param_reduce(const void* workspace, size_t workspace_bytes, i
  * addressed as base + (b*len + i)*ld + h*head_dim, so the packed [B,N,3,H,d] qkv buffer and the
  * [B,M,2,H,d] kv buffer are read in place.  head_dim in {32, 64}.  The rows of one head that a kernel keeps in
  * LDS (K,V for fwd and the dQ kernel; Q,dO for the dK/dV kernel) must fit 160 KiB: <= 568 rows at head_dim 64.
- * fwd also writes lse[B,H,q_len] (f32, natural log) for the backward.  bwd = two kernels (dQ per query block; dK,dV per
- * key tile, accumulated in registers: no atomics); workspace holds rowsum(dO*O) [B,H,q_len] f32. */
+ * fwd also writes lse[B,H,q_len] (f32, natural log) for the backward.  bwd = one kernel per (batch, head) with Q, dO, K, V
+ * in LDS when two such blocks fit a CU (the pretraining lengths), else two kernels (dQ per query block; dK,dV per key
+ * tile); accumulation in registers, no atomics; workspace holds rowsum(dO*O) [B,H,q_len] f32 for the two-kernel form. */
 int mmae_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
                   float* lse, int B, int H, int q_len, int kv_len, int head_dim, float scale, mmae_stream_t stream);
 size_t mmae_attn_bwd_workspace_bytes(int B, int H, int q_len);
@@ -118,6 +119,9 @@ int mmae_attn_bwd(const void* q, long ldq, const void* k, long ldk, const void* 
                   const void* d_o, long lddo, const float* lse, void* dq, long lddq, void* dk, long lddk, void* dv,
                   long lddv, int B, int H, int q_len, int kv_len, int head_dim, float scale, void* workspace,
                   size_t workspace_bytes, mmae_stream_t stream);
+/* Kernel choice for mmae_attn_bwd: 0 = by size (default), 1 = two kernels, 2 = one kernel whenever Q, dO, K, V of a head
+ * fit the 160 KiB LDS.  Process-wide; for tests and tuning. */
+void mmae_attn_bwd_set_variant(int variant);
 
 /* ---- masking (multimae/multimae.py:218-253) --------------------------------------------------
  * One workgroup per sample.  task_dist [B,T] f32 is the Dirichlet sample, noise [B,total] f32 the

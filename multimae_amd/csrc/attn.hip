@@ -352,6 +352,177 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs p, int n
 }
 
 // --------------------------------------------------------------------------------------------
+// backward, both kernels in one for sequences short enough that Q, dO, K and V of a head fit LDS together: every operand
+// is read from HBM once (the two-kernel form reads Q, dO, K, V twice and passes delta through a workspace), which is what
+// bounds attention at these lengths (99-token encoder: 15 GFLOP against 0.3 GB per layer).  After staging (delta =
+// rowsum(dO * O) is formed while dO is staged and stays in LDS) the block's work items are the 32-query dQ tiles followed
+// by the 32-key dK / dV tiles, dealt round-robin to the waves: same arithmetic as the two kernels above, every fragment
+// from LDS.
+// --------------------------------------------------------------------------------------------
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, int nqp, int nkp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LDR = D + 8, KS = D / 16, DT = D / 32, CH = D / 8;
+    bf16* Qs = (bf16*)smem;                    // [nqp][LDR]
+    bf16* dOs = Qs + nqp * LDR;                // [nqp][LDR]
+    bf16* Ks = dOs + nqp * LDR;                // [nkp][LDR]
+    bf16* Vs = Ks + nkp * LDR;                 // [nkp][LDR]
+    float* lse2 = (float*)(Vs + nkp * LDR);    // [nqp]
+    float* delta = lse2 + nqp;                 // [nqp]
+    float* kbar = delta + nqp;                 // [D]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h2 = lane >> 5;
+    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+
+    stage_rows<D>(p.q + (long)b * p.q_len * p.ldq + h * D, p.ldq, p.q_len, nqp, Qs, tid, NW * 64);
+    stage_rows<D>(p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.kv_len, nkp, Ks, tid, NW * 64);
+    stage_rows<D>(p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.kv_len, nkp, Vs, tid, NW * 64);
+    // dO with delta: CH adjacent lanes hold one row (nqp * CH is a multiple of 64, so whole waves run each iteration)
+    for (int idx = tid; idx < nqp * CH; idx += NW * 64) {
+        const int n = idx / CH, ch = idx - n * CH;
+        bf16x8 g;
+        float part = 0.f;
+        if (n < p.q_len) {
+            g = *(const bf16x8*)(p.dO + ((long)b * p.q_len + n) * p.lddo + h * D + ch * 8);
+            const bf16x8 of = *(const bf16x8*)(p.o + ((long)b * p.q_len + n) * p.ldo + h * D + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part += (float)g[e] * (float)of[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = (bf16)0.f;
+        }
+        *(bf16x8*)(dOs + n * LDR + ch * 8) = g;
+#pragma unroll
+        for (int m = 1; m < CH; m <<= 1) part += __shfl_xor(part, m, 64);
+        if (ch == 0) {
+            delta[n] = part;
+            lse2[n] = n < p.q_len ? p.lse[((long)b * p.H + h) * p.q_len + n] * LOG2E : 1e30f;  // padded rows: every probability 0
+        }
+    }
+    __syncthreads();
+    if (tid < D) {
+        float sum = 0.f;
+        for (int n = 0; n < p.kv_len; ++n) sum += (float)Ks[n * LDR + tid];
+        kbar[tid] = sum / (float)p.kv_len;
+    }
+    __syncthreads();
+
+    const float c = p.scale * LOG2E;
+    const int nqt = nqp / 32, nkt = nkp / 32;
+    const int tail = p.kv_len - (nkt - 1) * 32;
+
+    for (int item = wave; item < nqt + nkt; item += NW) {
+        if (item < nqt) {
+            // ---- dQ of a 32-query block (see attn_bwd_dq_kernel) ----
+            const int qrow = item * 32 + r;
+            bf16x8 qf[KS], dof[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                qf[ks] = row_frag<D>(Qs, qrow, ks, h2);
+                dof[ks] = row_frag<D>(dOs, qrow, ks, h2);
+            }
+            const float my_delta = delta[qrow], my_lse = lse2[qrow];
+            f32x16 dq[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
+            float rs = 0.f;
+            for (int kt = 0; kt < nkt; ++kt) {
+                f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Ks, kt * 32 + r, ks, h2), qf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vs, kt * 32 + r, ks, h2), dof[ks], dp, 0, 0, 0);
+                }
+                const int lim = kt == nkt - 1 ? tail : 32;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float pr = acc_row(i, h2) < lim ? __builtin_amdgcn_exp2f(s[i] * c - my_lse) : 0.f;
+                    s[i] = pr * (dp[i] - my_delta) * p.scale;
+                    rs += (float)(bf16)s[i];
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 dsf = pack8(s, s2);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+                        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ks, LDR, kt * 32 + 16 * s2, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
+                }
+            }
+            rs += __shfl_xor(rs, 32, 64);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dq[dt][i] -= rs * kbar[dt * 32 + acc_row(i, h2)];
+            if (qrow < p.q_len) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    bf16* op = p.dq + ((long)b * p.q_len + qrow) * p.lddq + h * D + dt * 32 + 4 * h2;
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        bf16x4 ov = {(bf16)dq[dt][4 * i4], (bf16)dq[dt][4 * i4 + 1], (bf16)dq[dt][4 * i4 + 2], (bf16)dq[dt][4 * i4 + 3]};
+                        *(bf16x4*)(op + 8 * i4) = ov;
+                    }
+                }
+            }
+        } else {
+            // ---- dK, dV of a 32-key tile (see attn_bwd_dkv_kernel) ----
+            const int key = (item - nqt) * 32 + r;
+            const bool key_valid = key < p.kv_len;
+            // the tile's own K / V fragments are re-read from LDS per query block (opaque row index, so that the reads
+            // are not hoisted): holding them would take 2 * D / 2 more registers than four waves per SIMD leave
+            f32x16 dk[DT], dv[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) { dk[dt] = zero16(); dv[dt] = zero16(); }
+            for (int qb = 0; qb < nqt; ++qb) {
+                int krow = key;
+                asm volatile("" : "+v"(krow));
+                f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Qs, qb * 32 + r, ks, h2), row_frag<D>(Ks, krow, ks, h2), s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(dOs, qb * 32 + r, ks, h2), row_frag<D>(Vs, krow, ks, h2), dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    const f32x4 lv = *(const f32x4*)(lse2 + qb * 32 + 8 * i4 + 4 * h2);
+                    const f32x4 dl = *(const f32x4*)(delta + qb * 32 + 8 * i4 + 4 * h2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * i4 + e;
+                        const float pr = key_valid ? __builtin_amdgcn_exp2f(s[i] * c - lv[e]) : 0.f;
+                        s[i] = pr;
+                        dp[i] = pr * (dp[i] - dl[e]) * p.scale;
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 pf = pack8(s, s2), dsf = pack8(dp, s2);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dOs, LDR, qb * 32 + 16 * s2, dt * 32, lane), pf, dv[dt], 0, 0, 0);
+                        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qs, LDR, qb * 32 + 16 * s2, dt * 32, lane), dsf, dk[dt], 0, 0, 0);
+                    }
+                }
+            }
+            if (key_valid) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    bf16* kp = p.dk + ((long)b * p.kv_len + key) * p.lddk + h * D + dt * 32 + 4 * h2;
+                    bf16* vp = p.dv + ((long)b * p.kv_len + key) * p.lddv + h * D + dt * 32 + 4 * h2;
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        bf16x4 a = {(bf16)dk[dt][4 * i4], (bf16)dk[dt][4 * i4 + 1], (bf16)dk[dt][4 * i4 + 2], (bf16)dk[dt][4 * i4 + 3]};
+                        bf16x4 c2 = {(bf16)dv[dt][4 * i4], (bf16)dv[dt][4 * i4 + 1], (bf16)dv[dt][4 * i4 + 2], (bf16)dv[dt][4 * i4 + 3]};
+                        *(bf16x4*)(kp + 8 * i4) = a;
+                        *(bf16x4*)(vp + 8 * i4) = c2;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------------
 #define ATTN_MAX_LDS (160 * 1024)
@@ -395,6 +566,26 @@ static int launch_dkv(const AttnArgs& a, hipStream_t s) {
                            a.B * a.H, NW * 64, s, a, nqp, reserved);
 }
 
+static int g_bwd_variant = 0;  // 0 = by size, 1 = two kernels, 2 = one kernel whenever the head fits LDS
+extern "C" void mmae_attn_bwd_set_variant(int v) { g_bwd_variant = v; }
+
+static size_t fused_lds_bytes(const AttnArgs& a, int D) {
+    return sizeof(bf16) * 2 * (size_t)(pad32(a.q_len) + pad32(a.kv_len)) * (D + 8) + sizeof(float) * (2 * pad32(a.q_len) + D);
+}
+template <int D, int NW>
+static int launch_fused(const AttnArgs& a, hipStream_t s) {
+    static bool reserved = false;
+    const size_t bytes = fused_lds_bytes(a, D);
+    if (bytes > 65536 && !reserved) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<D, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_MAX_LDS);
+        MMAE_REQUIRE(e == hipSuccess, MMAE_ELAUNCH, "attn_bwd: cannot reserve LDS: %s", hipGetErrorString(e));
+        reserved = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<D, NW>), dim3(a.B * a.H), dim3(NW * 64), bytes, s, a, pad32(a.q_len), pad32(a.kv_len));
+    MMAE_CHECK_LAUNCH("attn_bwd_fused");
+    return MMAE_OK;
+}
+
 static int check_common(const AttnArgs& a, int head_dim, const char* who) {
     MMAE_REQUIRE(a.q && a.k && a.v && a.o && a.lse, MMAE_EINVAL, "%s: null pointer", who);
     MMAE_REQUIRE(a.B > 0 && a.H > 0 && a.q_len > 0 && a.kv_len > 0, MMAE_EINVAL, "%s: empty problem", who);
@@ -436,6 +627,9 @@ extern "C" int mmae_attn_bwd(const void* q, long ldq, const void* k, long ldk, c
     MMAE_REQUIRE(workspace_bytes >= mmae_attn_bwd_workspace_bytes(B, H, q_len), MMAE_EWORKSPACE, "attn_bwd: workspace too small");
     MMAE_REQUIRE(lddo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 && (uintptr_t)d_o % 16 == 0, MMAE_ESHAPE,
                  "attn_bwd: bad gradient strides / alignment");
+    // one kernel when Q, dO, K, V of a head fit LDS twice per CU (two blocks keep 16 waves resident)
+    if (g_bwd_variant != 1 && fused_lds_bytes(a, head_dim) <= (g_bwd_variant == 2 ? (size_t)ATTN_MAX_LDS : (size_t)80 * 1024))
+        return head_dim == 64 ? launch_fused<64, 8>(a, stream) : launch_fused<32, 8>(a, stream);
     const bool wide_q = (q_len + 31) / 32 > 4, wide_k = (kv_len + 31) / 32 > 4;
     if (head_dim == 64) {
         rc = wide_q ? launch_dq<64, 8>(a, stream) : launch_dq<64, 4>(a, stream);

@@ -62,6 +62,11 @@ if __name__ == "__main__":
         o, lse = ops.attn_fwd(q, k_, v, B, H, nq, nk, d, d ** -0.5)
         do = r(B * nq, H * d)
         t = timeit(lambda: ops.attn_fwd(q, k_, v, B, H, nq, nk, d, d ** -0.5))
-        t2 = timeit(lambda: ops.attn_bwd(q, k_, v, o, do, lse, dq, dk, dv, B, H, nq, nk, d, d ** -0.5))
         fl = 4.0 * B * H * nq * nk * d
-        print(f"attn {name:10s}: fwd {t*1e6:7.1f} us {fl/t/1e12:6.1f} TF | bwd {t2*1e6:7.1f} us {2*fl/t2/1e12:6.1f} TF")
+        bw = []
+        for variant in (1, 2):
+            ops._L().mmae_attn_bwd_set_variant(variant)
+            t2 = timeit(lambda: ops.attn_bwd(q, k_, v, o, do, lse, dq, dk, dv, B, H, nq, nk, d, d ** -0.5))
+            bw.append(f"{t2*1e6:7.1f} us {2*fl/t2/1e12:6.1f} TF")
+        ops._L().mmae_attn_bwd_set_variant(0)
+        print(f"attn {name:10s}: fwd {t*1e6:7.1f} us {fl/t/1e12:6.1f} TF | bwd two kernels {bw[0]} | fused {bw[1]}")
