@@ -976,15 +976,27 @@ struct GemmTN {
 
 __device__ __forceinline__ int tn_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
+// Work item (tile, M-split) of a workgroup of the 1-D grid of 8 * ceil(tiles * splits / 8) workgroups.  Workgroups are
+// dealt to the 8 XCDs round-robin, each XCD with its own L2; the items, ordered split-major with the k-tile fastest, are cut
+// into 8 contiguous runs, one per XCD, so the workgroups resident on an XCD work on the same rows of X and Y and on
+// neighbouring column panels: each panel then leaves HBM about once instead of once per workgroup that uses it
+// (measured on dW fc1: 698 MB fetched per launch before, against 195 MB of operands).
+__device__ __forceinline__ bool tn_work_item(int tiles, int splits, int& tile, int& split) {
+    const int run = gridDim.x >> 3;
+    const int item = (blockIdx.x & 7) * run + (blockIdx.x >> 3);
+    split = item / tiles;
+    tile = item - split * tiles;
+    return item < tiles * splits;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int tiles, int splits) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;  // wave tile: 64 n x 64 k
     const int tiles_k = (p.K + 127) / 128;
-    const int nblk = gridDim.x;
-    const int wg = xcd_remap(blockIdx.x, nblk);
+    int wg, split;
+    if (!tn_work_item(tiles, splits, wg, split)) return;
     const int n0 = (wg / tiles_k) * 128, k0 = (wg % tiles_k) * 128;
-    const int split = blockIdx.y;
     const int m_begin = split * p.rows_per_split;
     int m_end = m_begin + p.rows_per_split; m_end = m_end < p.M ? m_end : p.M;
 
@@ -1099,11 +1111,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
 // the CUs once.  The bias gradient (column sums of X) is accumulated on the vector ALU from the X fragments already in
 // registers, each wave of a k-tile-0 workgroup taking two of its eight column fragments.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(GemmTN p, int tiles_k) {
+__global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(GemmTN p, int tiles_k, int tiles, int splits) {
     extern __shared__ __attribute__((aligned(16))) char tnsmem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 2, wk = wave & 3;
-    const int tile = blockIdx.x, split = blockIdx.y;
+    int tile, split;
+    if (!tn_work_item(tiles, splits, tile, split)) return;
     const int n0 = (tile / tiles_k) * 256, k0 = (tile % tiles_k) * 256;
     const int m_begin = split * p.rows_per_split;
     int m_end = m_begin + p.rows_per_split; m_end = m_end < p.M ? m_end : p.M;
@@ -1375,11 +1388,11 @@ extern "C" int mmae_gemm_tn(const void* X, long ldx, const void* Y, long ldy, in
             reserved = true;
         }
         const int tk = (K + 255) / 256, tiles = ((N + 255) / 256) * tk;
-        hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3(tiles, s), dim3(512), 2 * PP_KT_BYTES, stream, p, tk);
+        hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3((tiles * s + 7) / 8 * 8), dim3(512), 2 * PP_KT_BYTES, stream, p, tk, tiles, s);
         MMAE_CHECK_LAUNCH("gemm_tn_pp");
     } else {
         const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, s), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3((tiles * s + 7) / 8 * 8), dim3(256), 0, stream, p, tiles, s);
         MMAE_CHECK_LAUNCH("gemm_tn");
     }
     if (!direct && g_tn_phase != 1) {

@@ -145,7 +145,8 @@ class GradBuckets:
         self.pending = [b[2] for b in self.buckets]
         self.signalled = [False] * len(flat.named)
         self.works = []
-        self.enabled = self.world > 1
+        # a one-rank group still runs the collectives when asked to (MMAE_DP_SINGLE_RANK=1: exercises the RCCL path on one GPU)
+        self.enabled = self.world > 1 or (dist.is_initialized() and os.environ.get("MMAE_DP_SINGLE_RANK") == "1")
         if self.enabled:
             for i, (_, p) in enumerate(flat.named):
                 hook = self._make_hook(i)

@@ -36,6 +36,66 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _rccl_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      MMAE_DP_SINGLE_RANK="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dist.barrier()
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    from tests.test_gpu_model import _build, _losses
+    from multimae_amd.train import PretrainStep
+    cfg = O.small_cfg()
+    model = _build(cfg)
+    model.load_state_dict(G.perturbed_state(cfg, seed=7))
+    model.cuda()
+    step = PretrainStep(model, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05, bucket_mb=0.25, clip_grad=0.5)
+    assert step.world == 1 and step.buckets.enabled and len(step.buckets.buckets) > 3
+    x = {d: t.cuda() for d, t in G.seeded_inputs(cfg, B=4, seed=3).items()}
+    rnd = O.draw_mask_randomness(4, [16, 16], 1.0, torch.Generator().manual_seed(2))
+    for _ in range(2):
+        loss, _, gn2 = step(x, mask_randomness=rnd)
+    # the max-over-ranks reduction of bench.py
+    t = torch.tensor([1.5], device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    torch.cuda.synchronize()
+    torch.save({"params": step.flat.params.cpu(), "gn2": gn2.cpu(), "loss": loss.cpu(), "t": t.cpu()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _single_rank_reference():
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    from tests.test_gpu_model import _build, _losses
+    from multimae_amd.train import PretrainStep
+    cfg = O.small_cfg()
+    model = _build(cfg)
+    model.load_state_dict(G.perturbed_state(cfg, seed=7))
+    model.cuda()
+    step = PretrainStep(model, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05, clip_grad=0.5)
+    x = {d: t.cuda() for d, t in G.seeded_inputs(cfg, B=4, seed=3).items()}
+    rnd = O.draw_mask_randomness(4, [16, 16], 1.0, torch.Generator().manual_seed(2))
+    for _ in range(2):
+        loss, _, gn2 = step(x, mask_randomness=rnd)
+    return step, loss, gn2
+
+
+def test_rccl_bucket_path_with_a_one_rank_group(tmp_path):
+    """The RCCL process group (backend "nccl") as bench.py sets it up, with the bucketed all-reduces issued from the
+    gradient hooks on both streams: a one-rank group must reproduce the plain step bitwise."""
+    out = str(tmp_path / "rccl.pt")
+    port = 29900 + os.getpid() % 90
+    mp.spawn(_rccl_worker, args=(port, out), nprocs=1, join=True)
+    got = torch.load(out)
+    step, loss, gn2 = _single_rank_reference()
+    assert float(got["t"]) == 1.5
+    assert torch.equal(got["loss"], loss.cpu())
+    assert torch.equal(got["gn2"], gn2.cpu())
+    assert torch.equal(got["params"], step.flat.params.cpu())
+
+
 def test_two_rank_step_equals_single_rank_on_identical_batches(tmp_path):
     """Both ranks see the same batch and masks, so the averaged gradient is the single-rank gradient: (g + g) / 2 == g
     exactly, and two optimizer steps must land on bitwise identical parameters."""
