@@ -54,6 +54,9 @@ int mmae_gemm_nt(int epi, const void* A, long lda, const void* W, long ldw, int 
  * 4 = persistent 128x128 (2-stage ring), 5 = 256x256 eight-wave ping-pong kernel (K a multiple of 128, else as 0).
  * Process-wide; for tests and tuning. */
 void mmae_gemm_nt_set_variant(int variant);
+/* The 256x256 kernel may cut the last row panels into 128-row half tiles so that a thin last round of tiles is shared by
+ * twice as many CUs (default on); 0 switches that off.  Process-wide; for tests and tuning. */
+void mmae_gemm_nt_set_half_tiles(int on);
 /* Kernel used by the calling thread's last mmae_gemm_nt / patch-embed / un-patchify call (codes as above, never 0). */
 int mmae_gemm_nt_last_kernel(void);
 

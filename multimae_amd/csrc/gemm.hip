@@ -550,12 +550,17 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_persist32_kernel(GemmNT p, int
 // Slot images: 128 rows x 128 B; slot 0 / 3 hold activation rows {wm*128 + (0|64) + 0..63}, slot 1 / 2 weight rows
 // {wn*64 + (0|32) + 0..31}; 16-byte chunk c of row r sits at c ^ swz(r) (same two swizzles as the 128x128 kernel).
 // Requires K % 128 == 0 (k-tiles come in pairs, one per LDS buffer).
+// HALF: 128x256 tiles for the tail of a problem.  A workgroup owns a CU, so a last round with few tiles leaves most CUs
+// idle for a whole tile time; the launcher may instead give the last row panels to a second launch of this instance, in
+// which slot 0 holds 128 contiguous rows (64 per wave group, one 64x64 block per wave), slot 3 and the second
+// accumulator half do not exist and a k-tile has two phases: a tile costs a little over half a tile time and twice as
+// many CUs share the tail.
 // ------------------------------------------------------------------------------------------
 #define PP_H_BYTES 16384
 #define PP_KT_BYTES (4 * PP_H_BYTES)
 #define PP_LDS (2 * PP_KT_BYTES + 8 * 256)  // + per-wave bias slice (64 floats)
 
-template <int EPI>
+template <int EPI, bool HALF>
 __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char ppsmem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -569,7 +574,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
     const int total_kt = my_tiles * nk;
     float* bias_lds = (float*)(ppsmem + 2 * PP_KT_BYTES) + wave * 64;
 
-    auto tile_origin = [&](int t, int& m0, int& n0) {  // groups of 4 row-tiles x all column-tiles, rows fastest
+    auto tile_origin = [&](int t, int& m0, int& n0) {
+        if (HALF) {  // column tiles fastest: neighbouring workgroups share the 128 activation rows
+            const int hp = t / tiles_n;
+            m0 = hp * 128;
+            n0 = (t - hp * tiles_n) * 256;
+            return;
+        }
+        // groups of 4 row-tiles x all column-tiles, rows fastest
         const int per_group = 4 * tiles_n;
         const int grp = t / per_group, within = t - grp * per_group;
         int rows = tiles_m - grp * 4; rows = rows < 4 ? rows : 4;
@@ -588,7 +600,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
         for (int j = 0; j < 2; ++j) {
             const int r = (j * 8 + wave) * 8 + (lane >> 3);
             if (s == 0 || s == 3) {
-                int g = m0 + (r >> 6) * 128 + (s == 3 ? 64 : 0) + (r & 63);
+                int g = m0 + (HALF ? r : (r >> 6) * 128 + (s == 3 ? 64 : 0) + (r & 63));
                 g = g < p.M ? g : p.M - 1;
                 src[s][j] = p.A + (long)g * p.lda + (((lane & 7) ^ ((r >> 1) & 7)) << 3);
             } else {
@@ -600,6 +612,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
     };
     auto stage_slot = [&](auto slot_c) {
         constexpr int s = decltype(slot_c)::value;
+        if (HALF && s == 3) return;
         char* dst = ppsmem + (s_kt[s] & 1) * PP_KT_BYTES + s * PP_H_BYTES + wave * 1024;
         glds16(src[s][0], dst);
         glds16(src[s][1], dst + 8 * 1024);
@@ -622,17 +635,23 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
     using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
 #pragma unroll
     for (int s = 0; s < 4; ++s) { s_kt[s] = 0; s_tile[s] = me; }
-    set_slot(S0{}, me); set_slot(S1{}, me); set_slot(S2{}, me); set_slot(S3{}, me);
+    set_slot(S0{}, me); set_slot(S1{}, me); set_slot(S2{}, me);
+    if (!HALF) set_slot(S3{}, me);
 
-    // ---- prologue: 7 half-tiles in flight, the first k-tile landed ----
+    // ---- prologue: 7 half-tiles in flight, the first k-tile landed (HALF: 5 staged, slot 2 one k-tile behind) ----
     stage_slot(S0{}); stage_slot(S1{}); stage_slot(S2{}); stage_slot(S3{});
-    stage_slot(S0{}); stage_slot(S1{}); stage_slot(S2{});
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    stage_slot(S0{}); stage_slot(S1{});
+    if (HALF) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        stage_slot(S2{});
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
 
-    f32x4 acc[2][4][4];  // [A half][weight fragment][activation fragment]
+    f32x4 acc[HALF ? 1 : 2][4][4];  // [A half][weight fragment][activation fragment]
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < (HALF ? 1 : 2); ++h)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -676,6 +695,42 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const char* buf = ppsmem + b * PP_KT_BYTES;
+            if constexpr (HALF) {
+                // Two phases per k-tile.  Every LDS read is complete before the phase's first barrier, so a slot may be
+                // refilled in the phase after the one that reads it although the wave groups run one barrier apart:
+                // phase 1 refills slots 0 / 1 of this buffer (k-tile + 2), the next phase 0 refills slot 2.  Each
+                // phase waits for all but its three newest half-tiles: what the next phase reads has then landed.
+                // (A third k-tile buffer, i.e. one more k-tile of run-ahead, measured no faster: the phases are bound by
+                // LDS reads, 16 per wave and k-tile for half the MFMAs of a full tile.)
+                // ---- phase 0 ----
+                read_a(buf);
+                read_w(buf + PP_H_BYTES, wlo);
+                if (kt == 0 && b == 0 && p.bias) {
+                    int m0, n0;
+                    tile_origin(tile, m0, n0);
+                    int n = n0 + wn * 64 + lane; n = n < p.N ? n : p.N - 1;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + n),
+                                                     (__attribute__((address_space(3))) void*)bias_lds, 4, 0, 0);
+                }
+                stage_slot(S2{});
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_quad(acc[0], 0, wlo);
+                __builtin_amdgcn_s_barrier();
+                // ---- phase 1 ----
+                read_w(buf + 2 * PP_H_BYTES, whi);
+                stage_slot(S0{});
+                stage_slot(S1{});
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_quad(acc[0], 2, whi);
+                __builtin_amdgcn_s_barrier();
+                continue;
+            }
             // ---- phase 0 ----
             read_a(buf);
             read_w(buf + PP_H_BYTES, wlo);
@@ -707,14 +762,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
             __builtin_amdgcn_s_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            mfma_quad(acc[1], 2, whi);
+            mfma_quad(acc[HALF ? 0 : 1], 2, whi);
             __builtin_amdgcn_s_barrier();
             // ---- phase 3 ----
             stage_slot(S2{});
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // all but the newest three half-tiles: the next k-tile has landed
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            mfma_quad(acc[1], 0, wlo);
+            mfma_quad(acc[HALF ? 0 : 1], 0, wlo);
             __builtin_amdgcn_s_barrier();
         }
         kt += 2;
@@ -730,16 +785,18 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
                     for (int e = 0; e < 4; ++e) { bv[8 * u + e] = b0[e]; bv[8 * u + 4 + e] = b1[e]; }
                 }
             }
-            const bool full = m0 + 256 <= p.M && n0 + 256 <= p.N;  // workgroup-uniform
+            const bool full = m0 + (HALF ? 128 : 256) <= p.M && n0 + 256 <= p.N;  // workgroup-uniform
+            const int rb = m0 + wm * (HALF ? 64 : 128);                            // first row of this wave's block
+            constexpr int NH2 = HALF ? 1 : 2;
             if constexpr (EPI == EPI_DGELU) {
                 // the saved pre-activations of the whole 128x64 block first: one wait for them (and for the loads still in
                 // flight ahead of them) instead of one per half
-                bf16x8 hs[2][4][2];
+                bf16x8 hs[NH2][4][2];
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2)
+                for (int h2 = 0; h2 < NH2; ++h2)
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) {
-                        int m = m0 + wm * 128 + h2 * 64 + mi * 16 + fr;
+                        int m = rb + h2 * 64 + mi * 16 + fr;
                         m = m < p.M ? m : p.M - 1;
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
@@ -749,21 +806,21 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
                         }
                     }
                 if (full) {
-                    store_wave_tile<EPI, true, true>(p, acc[0], m0 + wm * 128, n0 + wn * 64, fr, fq, bv, hs[0]);
-                    store_wave_tile<EPI, true, true>(p, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, fr, fq, bv, hs[1]);
+                    store_wave_tile<EPI, true, true>(p, acc[0], rb, n0 + wn * 64, fr, fq, bv, hs[0]);
+                    if (!HALF) store_wave_tile<EPI, true, true>(p, acc[NH2 - 1], rb + 64, n0 + wn * 64, fr, fq, bv, hs[NH2 - 1]);
                 } else {
-                    store_wave_tile<EPI, false, true>(p, acc[0], m0 + wm * 128, n0 + wn * 64, fr, fq, bv, hs[0]);
-                    store_wave_tile<EPI, false, true>(p, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, fr, fq, bv, hs[1]);
+                    store_wave_tile<EPI, false, true>(p, acc[0], rb, n0 + wn * 64, fr, fq, bv, hs[0]);
+                    if (!HALF) store_wave_tile<EPI, false, true>(p, acc[NH2 - 1], rb + 64, n0 + wn * 64, fr, fq, bv, hs[NH2 - 1]);
                 }
             } else if (full) {
-                store_wave_tile<EPI, true, true>(p, acc[0], m0 + wm * 128, n0 + wn * 64, fr, fq, bv);
-                store_wave_tile<EPI, true, true>(p, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, fr, fq, bv);
+                store_wave_tile<EPI, true, true>(p, acc[0], rb, n0 + wn * 64, fr, fq, bv);
+                if (!HALF) store_wave_tile<EPI, true, true>(p, acc[NH2 - 1], rb + 64, n0 + wn * 64, fr, fq, bv);
             } else {
-                store_wave_tile<EPI, false, true>(p, acc[0], m0 + wm * 128, n0 + wn * 64, fr, fq, bv);
-                store_wave_tile<EPI, false, true>(p, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, fr, fq, bv);
+                store_wave_tile<EPI, false, true>(p, acc[0], rb, n0 + wn * 64, fr, fq, bv);
+                if (!HALF) store_wave_tile<EPI, false, true>(p, acc[NH2 - 1], rb + 64, n0 + wn * 64, fr, fq, bv);
             }
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < NH2; ++h)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -780,6 +837,32 @@ template <int EPI>
 static int launch_nt_pp(const GemmNT& p, hipStream_t s);
 
 static int g_num_cus = 0;
+static int num_cus();
+
+// Tile plan of the ping-pong kernel: full_panels row panels of 256 rows as 256x256 tiles, then (second launch) the rows
+// after them as 128x256 half tiles.  rounds = tile times the two launches take together, a round of half tiles counted
+// as PP_HALF_COST (measured 0.72-0.78 at K = 3072: a half tile reads 2/3 of the LDS bytes of a full one for half the
+// MFMAs, and the second launch has its own start-up, which is why short reductions, K < 512, keep full tiles).  The last
+// row panels go to half tiles when that lowers rounds: typically when the last round of full tiles would occupy at most
+// half of the CUs.
+#define PP_HALF_COST 0.75
+struct PpPlan { int full_panels, tiles_n, halves; double rounds; };
+static int g_pp_halves = 1;  // 0 switches the half tiles off (tuning)
+static PpPlan pp_plan(int M, int N, int K) {
+    const int G = num_cus();
+    const int tm = (M + 255) / 256, tn = (N + 255) / 256;
+    const int total = tm * tn;
+    PpPlan pl = {tm, tn, 0, (double)((total + G - 1) / G)};
+    const int rem = total % G;  // full tiles of the last round (0: that round is full)
+    if (!g_pp_halves || rem == 0 || K < 512) return pl;
+    int cut = (rem + tn - 1) / tn;  // row panels to cut: the full tiles then end at or before a round boundary
+    if (cut > tm) cut = tm;
+    const int full_panels = tm - cut;
+    const int halves = ((M - full_panels * 256 + 127) / 128) * tn;
+    const double r = (double)((full_panels * tn + G - 1) / G) + PP_HALF_COST * (double)((halves + G - 1) / G);
+    if (r < pl.rounds) { pl.full_panels = full_panels; pl.halves = halves; pl.rounds = r; }
+    return pl;
+}
 static int num_cus() {
     if (g_num_cus == 0) {
         int dev = 0, n = 0;
@@ -837,18 +920,42 @@ template <int EPI>
 static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
     static bool reserved = false;
     if (!reserved) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e != hipSuccess) {
             mmae_set_error("gemm_nt: cannot reserve %d bytes of LDS: %s", PP_LDS, hipGetErrorString(e));
             return MMAE_ELAUNCH;
         }
         reserved = true;
     }
-    const int tm = (p.M + 255) / 256, tn = (p.N + 255) / 256;
-    int grid = tm * tn;
-    if (grid > num_cus()) grid = num_cus();
-    hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(grid), dim3(512), PP_LDS, s, p, tm, tn);
-    MMAE_CHECK_LAUNCH("gemm_nt_pp");
+    // the row-mapped epilogues address output rows through tables of the whole problem: no second launch on a row offset
+    PpPlan pl = pp_plan(p.M, p.N, p.K);
+    if (EPI == EPI_TOKENS || EPI == EPI_UNPATCH) pl = {(p.M + 255) / 256, (p.N + 255) / 256, 0, 0.0};
+    if (pl.full_panels > 0) {
+        GemmNT q = p;
+        if (pl.halves) q.M = pl.full_panels * 256;
+        int grid = pl.full_panels * pl.tiles_n;
+        if (grid > num_cus()) grid = num_cus();
+        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, false>), dim3(grid), dim3(512), PP_LDS, s, q, pl.full_panels, pl.tiles_n);
+        MMAE_CHECK_LAUNCH("gemm_nt_pp");
+    }
+    if (pl.halves) {
+        // the rows after the full panels, as a problem of its own
+        const long r0 = (long)pl.full_panels * 256;
+        constexpr long out_sz = (EPI == EPI_RESID || EPI == EPI_F32) ? 4 : 2;
+        constexpr long aux_sz = EPI == EPI_RESID ? 4 : 2;
+        GemmNT q = p;
+        q.A = p.A + r0 * p.lda;
+        q.M = p.M - (int)r0;
+        q.out = (char*)p.out + r0 * p.ldo * out_sz;
+        if (p.out2) q.out2 = (char*)p.out2 + r0 * p.ldo * out_sz;
+        if (p.aux) q.aux = (const char*)p.aux + r0 * p.ldaux * aux_sz;
+        int grid = pl.halves;
+        if (grid > num_cus()) grid = num_cus();
+        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true>), dim3(grid), dim3(512), PP_LDS, s, q, (q.M + 127) / 128, pl.tiles_n);
+        MMAE_CHECK_LAUNCH("gemm_nt_pp(half tiles)");
+    }
     return MMAE_OK;
 }
 
@@ -860,27 +967,30 @@ extern "C" int mmae_gemm_tn_last_kernel(void) { return g_last_tn; }
 
 static int g_nt_variant = 0;  // 0 = choose by size, 1 = always 128x128, 2 = always persistent 256x128
 extern "C" void mmae_gemm_nt_set_variant(int v) { g_nt_variant = v; }
+extern "C" void mmae_gemm_nt_set_half_tiles(int on) { g_pp_halves = on; }
 
 template <int EPI>
 static int launch_nt(const GemmNT& p, hipStream_t s) {
     // Measured on MI355X at the shapes of the ViT-B step.  The 256x256 ping-pong kernel runs a k-tile in about 60 % of the
     // time the 128x128 kernels need per FLOP, but a workgroup owns a whole CU, so it pays only where the tile count
-    // fills the last round of CUs (N = 2304 / 3072 at M = 25344: 87 / 93 %, the decoder shapes at M = 50176: 77 %;
-    // N = 768 at M = 25344: 58 %, where it loses).  Among the
+    // fills the rounds of CUs, counting a tail of half tiles at its cost (N = 2304 / 3072 at M = 25344: 93 %, the decoder
+    // shapes at M = 50176: 77 %; N = 768 at M = 25344: 58 % with full tiles, where it loses, 66 % with half tiles).  Among the
     // 128x128 kernels the persistent ring wins for many tiles of a short K loop (N >= 2048), the plain grid elsewhere.
     const long tiles128 = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     if (g_nt_variant == 5 && p.K % 128 == 0) { g_last_nt = 5; return launch_nt_pp<EPI>(p, s); }
     if (g_nt_variant == 2) { g_last_nt = 2; return launch_nt_persist<EPI, 4, 3>(p, s); }
     if (g_nt_variant == 3) { g_last_nt = 3; return launch_nt_persist32<EPI>(p, s); }
-    if (g_nt_variant == 0 && p.K % 128 == 0 && EPI != EPI_RESID && EPI != EPI_TOKENS && EPI != EPI_UNPATCH) {
+    if (g_nt_variant == 0 && p.K % 128 == 0 && EPI != EPI_TOKENS && EPI != EPI_UNPATCH) {
         const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-        const long rounds = (tiles256 + num_cus() - 1) / num_cus();
-        const double fill = (double)tiles256 / (double)(rounds * num_cus());
-        static double min_fill = -1.0;
-        if (min_fill < 0.0) {
+        const double fill = (double)tiles256 / (pp_plan(p.M, p.N, p.K).rounds * num_cus());
+        static double env_fill = -1.0;
+        if (env_fill < 0.0) {
             const char* e = getenv("MMAE_PP_FILL");
-            min_fill = e ? atof(e) : 0.75;
+            env_fill = e ? atof(e) : 0.0;
         }
+        // long reductions amortise the tile start-up and the second launch better (measured at N = 768, M = 25344,
+        // fill 0.66: K = 3072 wins by 4-10 % over the 128x128 kernel, K = 768 loses by 5 %)
+        const double min_fill = env_fill > 0.0 ? env_fill : (p.K >= 2048 ? 0.65 : 0.75);
         if (fill >= min_fill) { g_last_nt = 5; return launch_nt_pp<EPI>(p, s); }
     }
     if (g_nt_variant == 4 || (g_nt_variant == 0 && p.N >= 2048 && tiles128 >= 4 * 2 * num_cus())) {

@@ -31,12 +31,13 @@ if __name__ == "__main__":
         bias = torch.randn(n, device="cuda")
         aux = r(m, n, dt=torch.float32) if epi == 2 else (r(m, n) if epi == 3 else None)
         res = []
-        for variant in (1, 2, 3, 4, 5):
-            ops._L().mmae_gemm_nt_set_variant(variant)
+        for variant in (1, 4, 6, 5, 0):  # 6 = ping-pong kernel with full tiles only
+            ops._L().mmae_gemm_nt_set_variant(min(variant, 5))
+            ops._L().mmae_gemm_nt_set_half_tiles(0 if variant == 6 else 1)
             t = timeit(lambda: ops.gemm_nt(epi, a, w, None if epi == 3 else bias, aux=aux))
             res.append(f"{t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
         ops._L().mmae_gemm_nt_set_variant(0)
-        print(f"gemm_nt {name:10s} M={m} N={n} K={k}: t128 {res[0]} | p256 {res[1]} | p256k32 {res[2]} | p128 {res[3]} | pp256 {res[4]}")
+        print(f"gemm_nt {name:10s} M={m} N={n} K={k}: t128 {res[0]} | p128 {res[1]} | pp256 full {res[2]} | pp256 {res[3]} | auto {res[4]}")
     if len(sys.argv) > 1 and sys.argv[1] == "nt":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tn":

@@ -27,11 +27,13 @@ def _randn(*shape, seed=0, dtype=torch.bfloat16, scale=1.0):
 
 
 # ---------------------------------------------------------------------------------------------- GEMM
-@pytest.fixture(params=[1, 2, 3, 4, 5], ids=["tile128", "persist256", "persist256k32", "persist128", "pingpong256"])
+@pytest.fixture(params=[1, 2, 3, 4, 5, 6], ids=["tile128", "persist256", "persist256k32", "persist128", "pingpong256", "pingpong256_full_tiles_only"])
 def nt_variant(request, ops):
-    ops._L().mmae_gemm_nt_set_variant(request.param)
+    ops._L().mmae_gemm_nt_set_variant(min(request.param, 5))
+    ops._L().mmae_gemm_nt_set_half_tiles(0 if request.param == 6 else 1)
     yield request.param
     ops._L().mmae_gemm_nt_set_variant(0)
+    ops._L().mmae_gemm_nt_set_half_tiles(1)
 
 
 @pytest.mark.parametrize("M,N,K", [(396, 2304, 768), (25344, 768, 768), (1000, 256, 256), (128, 3072, 768), (777, 768, 3072), (130, 2128, 256)])
