@@ -56,6 +56,27 @@ def cpu_baseline():
                       "(fwd + 3 losses + bwd + AdamW) after 2 warm-up, oracle/multimae_oracle.py CpuTrainer"}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed counter passes of this same command (rocprofv3 cannot run inside
+    the process it profiles): profiles/pmc_traffic.json, written by scripts/pmc_table.py from one --pmc FETCH_SIZE and one
+    --pmc WRITE_SIZE run, bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 tallies wide reads at half their size).
+    Launch-weighted mean over the grids the kernel ran with; (None, None) when the file or the kernel is missing."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    tot = cnt = 0
+    for key, v in table.items():
+        if kernel in key:
+            tot += v["hbm_bytes"] * v["launches"]
+            cnt += v["launches"]
+    if cnt == 0:
+        return None, None
+    return int(tot / cnt), "profiles/pmc_traffic.json"
+
+
 def main():
     args = parse()
     import torch
@@ -125,8 +146,10 @@ def main():
         # the dominant kernel = the single kernel (name as rocprofv3 prints it) with the most time per step
         name, (fl, sec, n) = max(((k_, v) for k_, v in ker.items() if v[0] > 0), key=lambda kv: kv[1][1])
         ach = fl / sec / 1e12
+        traffic, traffic_src = pmc_traffic(name)
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": n // 2,
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "launches_per_step": n // 2,
                 "avg_launch_us": round(sec / n * 1e6, 1),
                 "kernels": {k_: {"tflops": round(v[0] / v[1] / 1e12, 1) if v[0] > 0 else None, "ms_per_step": round(v[1] / 2 * 1e3, 3),
                                  "launches_per_step": v[2] // 2, "avg_launch_us": round(v[1] / v[2] * 1e6, 1)}

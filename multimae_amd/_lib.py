@@ -17,6 +17,8 @@ SIGNATURES = {
     "mmae_gemm_nt": (_i, [_i, _p, _l, _p, _l, _i, _i, _i, _p, _p, _l, _p, _p, _l, _p]),
     "mmae_gemm_tn_set_variant": (None, [_i]),
     "mmae_gemm_nt_set_half_tiles": (None, [_i]),
+    "mmae_gemm_nt_set_phase": (None, [_i]),
+    "mmae_gemm_nt_last_full_rows": (_i, []),
     "mmae_gemm_nt_last_kernel": (_i, []),
     "mmae_gemm_tn_last_kernel": (_i, []),
     "mmae_gemm_tn_set_phase": (None, [_i]),

@@ -835,6 +835,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
 
 template <int EPI>
 static int launch_nt_pp(const GemmNT& p, hipStream_t s);
+// For timing the two launches of the ping-pong path separately: 0 = both (default), 1 = the full-tile launch only,
+// 2 = the half-tile launch only.  g_nt_full_rows: rows covered by full tiles in this thread's last gemm_nt call.
+static thread_local int g_nt_phase = 0, g_nt_full_rows = 0;
 
 static int g_num_cus = 0;
 static int num_cus();
@@ -932,7 +935,8 @@ static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
     // the row-mapped epilogues address output rows through tables of the whole problem: no second launch on a row offset
     PpPlan pl = pp_plan(p.M, p.N, p.K);
     if (EPI == EPI_TOKENS || EPI == EPI_UNPATCH) pl = {(p.M + 255) / 256, (p.N + 255) / 256, 0, 0.0};
-    if (pl.full_panels > 0) {
+    g_nt_full_rows = pl.halves ? pl.full_panels * 256 : p.M;
+    if (pl.full_panels > 0 && g_nt_phase != 2) {
         GemmNT q = p;
         if (pl.halves) q.M = pl.full_panels * 256;
         int grid = pl.full_panels * pl.tiles_n;
@@ -940,7 +944,7 @@ static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
         hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, false>), dim3(grid), dim3(512), PP_LDS, s, q, pl.full_panels, pl.tiles_n);
         MMAE_CHECK_LAUNCH("gemm_nt_pp");
     }
-    if (pl.halves) {
+    if (pl.halves && g_nt_phase != 1) {
         // the rows after the full panels, as a problem of its own
         const long r0 = (long)pl.full_panels * 256;
         constexpr long out_sz = (EPI == EPI_RESID || EPI == EPI_F32) ? 4 : 2;
@@ -968,6 +972,8 @@ extern "C" int mmae_gemm_tn_last_kernel(void) { return g_last_tn; }
 static int g_nt_variant = 0;  // 0 = choose by size, 1 = always 128x128, 2 = always persistent 256x128
 extern "C" void mmae_gemm_nt_set_variant(int v) { g_nt_variant = v; }
 extern "C" void mmae_gemm_nt_set_half_tiles(int on) { g_pp_halves = on; }
+extern "C" void mmae_gemm_nt_set_phase(int phase) { g_nt_phase = phase; }
+extern "C" int mmae_gemm_nt_last_full_rows(void) { return g_nt_full_rows; }
 
 template <int EPI>
 static int launch_nt(const GemmNT& p, hipStream_t s) {
@@ -977,6 +983,7 @@ static int launch_nt(const GemmNT& p, hipStream_t s) {
     // shapes at M = 50176: 77 %; N = 768 at M = 25344: 58 % with full tiles, where it loses, 66 % with half tiles).  Among the
     // 128x128 kernels the persistent ring wins for many tiles of a short K loop (N >= 2048), the plain grid elsewhere.
     const long tiles128 = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    g_nt_full_rows = p.M;
     if (g_nt_variant == 5 && p.K % 128 == 0) { g_last_nt = 5; return launch_nt_pp<EPI>(p, s); }
     if (g_nt_variant == 2) { g_last_nt = 2; return launch_nt_persist<EPI, 4, 3>(p, s); }
     if (g_nt_variant == 3) { g_last_nt = 3; return launch_nt_persist32<EPI>(p, s); }

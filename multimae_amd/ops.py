@@ -48,7 +48,7 @@ PROFILE = None
 
 
 _NT_KERNELS = {1: "gemm_nt_kernel<%d>", 2: "gemm_nt_persist_kernel<%d, 4, 3>", 3: "gemm_nt_persist32_kernel<%d>",
-               4: "gemm_nt_persist_kernel<%d, 2, 2>", 5: "gemm_nt_pp_kernel<%d>"}
+               4: "gemm_nt_persist_kernel<%d, 2, 2>", 5: "gemm_nt_pp_kernel<%d, false>"}
 _TN_KERNELS = {1: "gemm_tn_kernel", 2: "gemm_tn_pp_kernel"}
 
 
@@ -72,7 +72,9 @@ class _Timed:
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.name, self.flops, self.e0, self.e1, self.label() if callable(self.label) else (self.label or self.name)))
+            flops = self.flops() if callable(self.flops) else self.flops
+            if flops is not None:  # None: nothing was launched
+                PROFILE.append((self.name, flops, self.e0, self.e1, self.label() if callable(self.label) else (self.label or self.name)))
         return False
 
 
@@ -112,9 +114,22 @@ def gemm_nt(epi: int, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Ten
         _, _, ldaux = _rows2d(aux, "gemm_nt aux")
     if bias is not None:
         _req(bias, F32, "gemm_nt bias")
-    with _Timed("gemm_nt", 2.0 * M * N * K, lambda: _nt_label(epi)):
-        _lib.check(_L().mmae_gemm_nt(epi, _ptr(a), lda, _ptr(w), ldw, M, N, K, _ptr(bias), _ptr(out), ldo, _ptr(out2),
-                                     _ptr(aux), ldaux, _stream()), "gemm_nt")
+    args = (epi, _ptr(a), lda, _ptr(w), ldw, M, N, K, _ptr(bias), _ptr(out), ldo, _ptr(out2), _ptr(aux), ldaux)
+    if PROFILE is None:
+        _lib.check(_L().mmae_gemm_nt(*args, _stream()), "gemm_nt")
+    else:  # the 256x256 path may be two launches (full tiles, then half tiles for the last rows): time each as the kernel it is
+        L = _L()
+        try:
+            L.mmae_gemm_nt_set_phase(1)
+            full = lambda: L.mmae_gemm_nt_last_full_rows()
+            with _Timed("gemm_nt", lambda: 2.0 * full() * N * K if full() > 0 else None, lambda: _nt_label(epi)):
+                _lib.check(L.mmae_gemm_nt(*args, _stream()), "gemm_nt")
+            if full() < M:
+                L.mmae_gemm_nt_set_phase(2)
+                with _Timed("gemm_nt", 2.0 * (M - full()) * N * K, "gemm_nt_pp_kernel<%d, true>" % epi):
+                    _lib.check(L.mmae_gemm_nt(*args, _stream()), "gemm_nt")
+        finally:
+            L.mmae_gemm_nt_set_phase(0)
     return (out, out2) if epi == EPI_GELU else out
 
 
