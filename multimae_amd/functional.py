@@ -101,11 +101,45 @@ def _side(device):
 
 
 def join_side_stream(device=None):
-    """Make the current stream wait for the weight-gradient stream (call before gradients are read)."""
+    """Make the current stream wait for the weight-gradient stream and the decoder streams (call before gradients are
+    read: after backward, before the gradient norm, the optimizer step or zero_grad)."""
+    join_aux_streams(device)
     for idx, ent in _SIDE.items():
         if ent[1] and (device is None or torch.device(device).index in (None, idx)):
             torch.cuda.current_stream(idx).wait_stream(ent[0])
             ent[1] = False
+
+
+# The output adapters (decoders) are independent of each other between the encoder output and the losses, and their
+# GEMMs are small (196 tiles of 256x256 on 256 CUs, short K): each runs on a stream of its own so that the workgroups of
+# one fill the CUs another leaves idle.  Autograd runs every backward node on the stream its forward ran on.
+DECODER_STREAMS = os.environ.get("MMAE_DEC_STREAMS", "1") != "0"
+_AUX = {}  # device index -> [streams, used since the last join]
+
+
+def aux_streams(device, n: int):
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    ent = _AUX.get(idx)
+    if ent is None:
+        ent = _AUX[idx] = [[], False]
+    while len(ent[0]) < n:
+        ent[0].append(torch.cuda.Stream(device=idx))
+    ent[1] = True
+    return ent[0][:n]
+
+
+def join_aux_streams(device=None, reset: bool = True):
+    """Make the current stream wait for the decoder streams (before anything reads what their kernels wrote in place)."""
+    for idx, ent in _AUX.items():
+        if ent[1] and (device is None or torch.device(device).index in (None, idx)):
+            cur = torch.cuda.current_stream(idx)
+            for st in ent[0]:
+                if st != cur:
+                    cur.wait_stream(st)
+            if reset:
+                ent[1] = False
 
 
 def side_stream_pending(device) -> Optional[torch.cuda.Stream]:

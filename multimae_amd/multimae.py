@@ -204,10 +204,24 @@ class MultiMAE(nn.Module):
         # Adapters listed in fp32_output_adapters (reference: multimae/multimae.py:426-436 runs them outside autocast)
         # return their predictions as the un-rounded fp32 accumulators of out_proj; the matrix products themselves keep
         # bf16 operands with fp32 accumulation like every other product of the step.
-        preds = {d: self.output_adapters[d](encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep,
-                                            ids_restore=ids_restore, fp32_output=d in fp32_output_adapters)
-                 for d in self.output_adapters}
-        return preds, task_masks
+        def decode(d):
+            return self.output_adapters[d](encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep,
+                                           ids_restore=ids_restore, fp32_output=d in fp32_output_adapters)
+        if Fn.DECODER_STREAMS and encoder_tokens.is_cuda and len(self.output_adapters) > 1:
+            # one stream per decoder (they are independent until the losses); same kernels, same order per decoder, so the
+            # results do not change
+            main = torch.cuda.current_stream(encoder_tokens.device)
+            streams = Fn.aux_streams(encoder_tokens.device, len(self.output_adapters))
+            preds = {}
+            for st, d in zip(streams, self.output_adapters):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    preds[d] = decode(d)
+            for st, d in zip(streams, self.output_adapters):
+                main.wait_stream(st)
+                preds[d].record_stream(main)
+            return preds, task_masks
+        return {d: decode(d) for d in self.output_adapters}, task_masks
 
 
 class MultiViT(MultiMAE):

@@ -171,6 +171,8 @@ class GradBuckets:
         weight-gradient stream (functional._lin_grads).  The collective is issued from a stream that waits for both."""
         s, e, _ = self.buckets[b]
         buf = self.flat.grads[s:e]
+        if buf.is_cuda:  # kernels of several decoder streams may have written into this bucket
+            Fn.join_aux_streams(buf.device, reset=False)
         side = Fn.side_stream_pending(buf.device) if buf.is_cuda else None
         if side is None:
             self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -499,3 +499,31 @@ def test_reference_style_loop_with_utils_helpers():
         assert torch.equal(loss.detach(), la) and torch.equal(norm, gn2.sqrt())
     assert all(torch.equal(p, q) for p, q in zip(a.state_dict().values(), b.state_dict().values()))
     assert U.get_rank() == 0 and U.get_world_size() == 1 and U.is_main_process()
+
+
+def test_decoder_streams_do_not_change_the_step():
+    """One stream per output adapter (default) against everything on one stream: same kernels in the same order per
+    decoder, so three optimisation steps must end on bitwise identical parameters."""
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    from multimae_amd import functional as Fn
+    from multimae_amd.train import PretrainStep
+    cfg = O.small_cfg()
+    x = {d: t.cuda() for d, t in G.seeded_inputs(cfg, B=4, seed=3).items()}
+    rnd = O.draw_mask_randomness(4, [16, 16], 1.0, torch.Generator().manual_seed(2))
+    res, saved = [], Fn.DECODER_STREAMS
+    try:
+        for flag in (True, False):
+            Fn.DECODER_STREAMS = flag
+            model = _build(cfg)
+            model.load_state_dict(G.perturbed_state(cfg, seed=7))
+            model.cuda()
+            step = PretrainStep(model, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05, clip_grad=1.0)
+            for _ in range(3):
+                loss, _, gn2 = step(x, mask_randomness=rnd)
+            torch.cuda.synchronize()
+            res.append((step.flat.params.clone(), loss.clone(), gn2.clone()))
+    finally:
+        Fn.DECODER_STREAMS = saved
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
