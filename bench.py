@@ -125,16 +125,16 @@ def main():
     if not args.no_roofline:
         # Two more steps with a HIP-event pair around every GEMM / attention launch (on the stream it is launched on).
         # Every rank runs them (the step holds collectives); rank 0 records.  The weight-gradient stream is switched off
-        # here so that a kernel's duration is its own, not that of two kernels sharing the chip.
+        # here, and so are the per-decoder streams, so that a kernel's duration is its own, not that of kernels sharing the chip.
         from multimae_amd import functional as Fn
-        side = Fn.SIDE_STREAM_DW
-        Fn.SIDE_STREAM_DW = False
+        side, dec = Fn.SIDE_STREAM_DW, Fn.DECODER_STREAMS
+        Fn.SIDE_STREAM_DW = Fn.DECODER_STREAMS = False
         if rank == 0:
             ops.PROFILE = []
         for _ in range(2):
             step(batch)
         sync()
-        Fn.SIDE_STREAM_DW = side
+        Fn.SIDE_STREAM_DW, Fn.DECODER_STREAMS = side, dec
     if roof is None and not args.no_roofline and rank == 0:
         fam, ker = {}, {}
         for name, flops, e0, e1, label in ops.PROFILE:
