@@ -23,7 +23,8 @@ def r(*s, dt=torch.bfloat16):
 
 if __name__ == "__main__":
     M = 25344
-    shapes_nt = [("qkv", M, 2304, 768, 0), ("proj+res", M, 768, 768, 2), ("fc1+gelu", M, 3072, 768, 1), ("fc2+res", M, 768, 3072, 2),
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    shapes_nt = [] if only in ("tn", "attn") else [("qkv", M, 2304, 768, 0), ("proj+res", M, 768, 768, 2), ("fc1+gelu", M, 3072, 768, 1), ("fc2+res", M, 768, 3072, 2),
                  ("dgelu", M, 3072, 768, 3), ("dLN fc1", M, 768, 3072, 0), ("dec fc1", 50176, 1024, 256, 1), ("dec qkv", 50176, 768, 256, 0),
                  ("dec fc2", 50176, 256, 1024, 2), ("pctx", M, 256, 768, 0)]
     for name, m, n, k, epi in shapes_nt:
@@ -42,7 +43,7 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tn":
         pass
-    for name, m, n, k in [("dW qkv", M, 2304, 768), ("dW proj", M, 768, 768), ("dW fc1", M, 3072, 768), ("dW fc2", M, 768, 3072),
+    for name, m, n, k in [] if only == "attn" else [("dW qkv", M, 2304, 768), ("dW proj", M, 768, 768), ("dW fc1", M, 3072, 768), ("dW fc2", M, 768, 3072),
                           ("dW dec fc1", 50176, 1024, 256), ("dW dec proj", 50176, 256, 256)]:
         x, y = r(m, n), r(m, k)
         out = torch.zeros(n, k, device="cuda"); cs = torch.zeros(n, device="cuda")
