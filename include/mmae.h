@@ -50,9 +50,8 @@ int mmae_gemm_nt(int epi, const void* A, long lda, const void* W, long ldw, int 
                  void* out, long ldo, void* out2, const void* aux, long ldaux, mmae_stream_t stream);
 
 /* Kernel choice for mmae_gemm_nt and its two siblings below: 0 = by problem size (default), 1 = always the 128x128
- * two-workgroups-per-CU kernel, 2 = persistent 256x128 (3-stage ring), 3 = persistent 256x128 with 32-deep stages,
- * 4 = persistent 128x128 (2-stage ring), 5 = 256x256 eight-wave ping-pong kernel (K a multiple of 128, else as 0).
- * Process-wide; for tests and tuning. */
+ * two-workgroups-per-CU kernel, 4 = persistent 128x128 (2-stage ring), 5 = 256x256 eight-wave ping-pong kernel (K a
+ * multiple of 128, else as 0).  Process-wide; for tests and tuning. */
 void mmae_gemm_nt_set_variant(int variant);
 /* The 256x256 kernel may cut the last row panels into 128-row half tiles so that a thin last round of tiles is shared by
  * twice as many CUs (default on); 0 switches that off.  Process-wide; for tests and tuning. */

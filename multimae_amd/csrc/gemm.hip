@@ -266,15 +266,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Persistent 256x128 variant for the large problems.  A 128x128 tile moves 1 byte from L2 per 64 FLOP and tops out
-// near 0.9 PFLOP/s on L2 -> LDS bandwidth; 256x128 halves the W traffic per FLOP.  Eight waves (4 x 2, 64x64 each),
-// one workgroup per CU, a 3-stage LDS ring filled two k-tiles ahead by 16-byte LDS-DMA, counted vmcnt + raw
-// s_barrier so the prefetch stays in flight across barriers, and the ring runs on across tile boundaries (the next
-// tile's first k-tiles are already landing while this tile's epilogue stores).
+// Persistent variant of the 128x128 kernel for problems with many tiles of a short K loop whose K is not a multiple
+// of 128 (the 256x256 kernel takes the others): waves 2 x 2 (WM = 2; WM = 4 gives a 256x128 tile), two workgroups per
+// CU, an LDS ring of STAGES k-tiles filled ahead by 16-byte LDS-DMA, counted vmcnt + raw s_barrier so the prefetch
+// stays in flight across barriers, and the ring runs on across tile boundaries (the next tile's first k-tiles are
+// already landing while this tile's epilogue stores).
 // ------------------------------------------------------------------------------------------
-#define PBM 256
-#define PSTAGE_BYTES 49152  // A 256x64 bf16 (32 KiB) + W 128x64 bf16 (16 KiB)
-#define PSTAGES 3
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -409,125 +406,6 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 ? 2 : 2)) void gemm_nt_persist_k
         // the LDS reads above were consumed by the MFMAs, so after the barrier stage it % STAGES may be refilled
         if (STAGES == 3 && more) wait_vmcnt<LOADS>();
         else wait_vmcnt<0>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-}
-
-// Same ring with 32-deep stages (24 KiB each, 72 KiB per workgroup): two workgroups per CU, so the two waves of a SIMD
-// belong to different workgroups and run out of phase (one computes while the other waits at its barrier).
-// 64-byte LDS rows: chunk c of row r sits at c ^ T[(r >> 2) & 3] (activation tile) or c ^ T[(r >> 3) & 3] (weight tile,
-// whose fragment rows are interleaved), T = {0,2,3,1}: every ds_read_b128 lane group then covers 16 distinct 16-byte slots.
-#define P32_STAGE_BYTES 24576  // A 256x32 bf16 (16 KiB) + W 128x32 bf16 (8 KiB)
-__device__ __forceinline__ int swz32(int a) { return (0x78 >> (2 * a)) & 3; }  // T = {0,2,3,1}
-
-template <int EPI>
-__global__ __launch_bounds__(512, 4) void gemm_nt_persist32_kernel(GemmNT p, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) char psmem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int chunk = (fq ^ swz32(fr >> 2)) << 4;  // both tiles: the lane's swizzle key is fr >> 2
-    const int wrow = wn * 64 + 8 * (fr >> 2) + (fr & 3);
-    const int ntiles = tiles_m * tiles_n, G = gridDim.x;
-    const int me = xcd_remap(blockIdx.x, G);
-    const int nk = (p.K + 31) / 32;
-    const int my_tiles = me < ntiles ? (ntiles - 1 - me) / G + 1 : 0;
-    const int total = my_tiles * nk;
-
-    auto tile_origin = [&](int t, int& m0, int& n0) {
-        const int per_group = 4 * tiles_n;
-        const int grp = t / per_group, within = t - grp * per_group;
-        int rows = tiles_m - grp * 4; rows = rows < 4 ? rows : 4;
-        m0 = (grp * 4 + within % rows) * PBM;
-        n0 = (within / rows) * BN;
-    };
-
-    const bf16* a_src[2]; const bf16* w_src;
-    int ka_src[2], kw_src;
-    int ld_tile = me, ld_kt = 0, ld_it = 0;
-    auto set_sources = [&](int t) {
-        int m0, n0;
-        tile_origin(t, m0, n0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {  // 16 rows of 64 B per wave-instruction
-            const int r = (j * 8 + wave) * 16 + (lane >> 2);
-            const int ca = (lane & 3) ^ swz32((r >> 2) & 3);
-            int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
-            a_src[j] = p.A + (long)gm * p.lda + ca * 8;
-            ka_src[j] = ca * 8;
-        }
-        const int r = wave * 16 + (lane >> 2);
-        const int cw = (lane & 3) ^ swz32((r >> 3) & 3);
-        int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
-        w_src = p.W + (long)gn * p.ldw + cw * 8;
-        kw_src = cw * 8;
-    };
-    auto issue = [&]() {
-        char* sa = psmem + (ld_it % PSTAGES) * P32_STAGE_BYTES;
-        char* sw = sa + 16384;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const void* as = ld_kt * 32 + ka_src[j] < p.K ? (const void*)(a_src[j] + ld_kt * 32) : (const void*)g_zero_page;
-            glds16(as, sa + (j * 8 + wave) * 1024);
-        }
-        const void* ws = ld_kt * 32 + kw_src < p.K ? (const void*)(w_src + ld_kt * 32) : (const void*)g_zero_page;
-        glds16(ws, sw + wave * 1024);
-        ++ld_it;
-        if (++ld_kt == nk) {
-            ld_kt = 0;
-            ld_tile += G;
-            if (ld_tile < ntiles) set_sources(ld_tile);
-        }
-    };
-
-    if (total == 0) return;
-    set_sources(ld_tile);
-    issue();
-    if (total > 1) {
-        issue();
-        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    int tile = me, kt = 0;
-    for (int it = 0; it < total; ++it) {
-        const bool more = ld_it < total;
-        if (more) issue();
-        const char* sa = psmem + (it % PSTAGES) * P32_STAGE_BYTES;
-        const char* sw = sa + 16384;
-        bf16x8 wf[4], af[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            wf[t] = *(const bf16x8*)(sw + (wrow + 32 * (t >> 1) + 4 * (t & 1)) * 64 + chunk);
-            af[t] = *(const bf16x8*)(sa + (wm * 64 + t * 16 + fr) * 64 + chunk);
-        }
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-        if (++kt == nk) {
-            int m0, n0;
-            tile_origin(tile, m0, n0);
-            store_wave_tile<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            kt = 0;
-            tile += G;
-        }
-        if (more) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -899,27 +777,6 @@ static int launch_nt_persist(const GemmNT& p, hipStream_t s) {
 }
 
 template <int EPI>
-static int launch_nt_persist32(const GemmNT& p, hipStream_t s) {
-    static bool reserved = false;
-    constexpr int lds = PSTAGES * P32_STAGE_BYTES;
-    if (!reserved) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_persist32_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) {
-            mmae_set_error("gemm_nt: cannot reserve %d bytes of LDS: %s", lds, hipGetErrorString(e));
-            return MMAE_ELAUNCH;
-        }
-        reserved = true;
-    }
-    const int tm = (p.M + PBM - 1) / PBM, tn = (p.N + BN - 1) / BN;
-    int grid = tm * tn;
-    const int slots = 2 * num_cus();
-    if (grid > slots) grid = slots;
-    hipLaunchKernelGGL(gemm_nt_persist32_kernel<EPI>, dim3(grid), dim3(512), lds, s, p, tm, tn);
-    MMAE_CHECK_LAUNCH("gemm_nt_persist32");
-    return MMAE_OK;
-}
-
-template <int EPI>
 static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
     static bool reserved = false;
     if (!reserved) {
@@ -969,7 +826,7 @@ static thread_local int g_last_nt = 0, g_last_tn = 0;  // kernel chosen by this 
 extern "C" int mmae_gemm_nt_last_kernel(void) { return g_last_nt; }
 extern "C" int mmae_gemm_tn_last_kernel(void) { return g_last_tn; }
 
-static int g_nt_variant = 0;  // 0 = choose by size, 1 = always 128x128, 2 = always persistent 256x128
+static int g_nt_variant = 0;  // 0 = choose by size, 1 = 128x128 grid kernel, 4 = persistent 128x128, 5 = 256x256 ping-pong
 extern "C" void mmae_gemm_nt_set_variant(int v) { g_nt_variant = v; }
 extern "C" void mmae_gemm_nt_set_half_tiles(int on) { g_pp_halves = on; }
 extern "C" void mmae_gemm_nt_set_phase(int phase) { g_nt_phase = phase; }
@@ -985,8 +842,6 @@ static int launch_nt(const GemmNT& p, hipStream_t s) {
     const long tiles128 = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     g_nt_full_rows = p.M;
     if (g_nt_variant == 5 && p.K % 128 == 0) { g_last_nt = 5; return launch_nt_pp<EPI>(p, s); }
-    if (g_nt_variant == 2) { g_last_nt = 2; return launch_nt_persist<EPI, 4, 3>(p, s); }
-    if (g_nt_variant == 3) { g_last_nt = 3; return launch_nt_persist32<EPI>(p, s); }
     if (g_nt_variant == 0 && p.K % 128 == 0 && EPI != EPI_TOKENS && EPI != EPI_UNPATCH) {
         const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         const double fill = (double)tiles256 / (pp_plan(p.M, p.N, p.K).rounds * num_cus());
