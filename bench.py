@@ -85,10 +85,12 @@ def main():
     from multimae_amd.builders import build_losses, build_multimae
     from multimae_amd.train import PretrainStep, init_distributed_mode
 
-    rank, world, local = init_distributed_mode("nccl")
+    # Rehearsal switches (not used by the measured runs): MMAE_BENCH_BACKEND=gloo and MMAE_BENCH_DEVICE=0 let several ranks
+    # share one GPU, which RCCL refuses, to exercise the multi-rank control flow on a one-GPU box.
+    rank, world, local = init_distributed_mode(os.environ.get("MMAE_BENCH_BACKEND", "nccl"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", int(os.environ.get("MMAE_BENCH_DEVICE", local)))
     torch.cuda.set_device(dev)
 
     torch.manual_seed(0)  # identical initial weights on every rank (stands for DDP's rank-0 broadcast)
@@ -98,20 +100,33 @@ def main():
     B = args.batch
     batch = {"rgb": torch.randn(B, 3, 224, 224, device=dev), "depth": torch.rand(B, 1, 224, 224, device=dev)}
 
+    verbose = os.environ.get("MMAE_BENCH_VERBOSE") == "1"
+    if verbose:  # where every thread stands if the run is still going after a minute
+        import faulthandler
+        faulthandler.dump_traceback_later(60, repeat=False, file=sys.stderr)
+
+    def note(msg):
+        if verbose:
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
     def sync():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    note("model built")
+    for i in range(args.warmup):
         loss, _, _ = step(batch)
+        note(f"warm-up step {i} enqueued")
     sync()
+    note("warm-up done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, task_losses, gn2 = step(batch)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    note("timed steps done")
+    if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -134,6 +149,7 @@ def main():
         for _ in range(2):
             step(batch)
         sync()
+        note("per-kernel timing steps done")
         Fn.SIDE_STREAM_DW, Fn.DECODER_STREAMS = side, dec
     if roof is None and not args.no_roofline and rank == 0:
         fam, ker = {}, {}
@@ -175,7 +191,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

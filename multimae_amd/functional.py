@@ -117,6 +117,17 @@ DECODER_STREAMS = os.environ.get("MMAE_DEC_STREAMS", "1") != "0"
 _AUX = {}  # device index -> [streams, used since the last join]
 
 
+def decoder_streams_enabled() -> bool:
+    """Single-rank runs only.  A process gets 4 hardware queues (GPU_MAX_HW_QUEUES); streams beyond that share one, and
+    kernels of streams that share a queue run in submission order.  With the main, weight-gradient and RCCL streams a
+    multi-rank step already uses three; three more would put a compute stream behind the all-reduce kernels, which stay
+    resident until every peer has arrived, and the overlap of communication with backward would be lost."""
+    if not DECODER_STREAMS:
+        return False
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
 def aux_streams(device, n: int):
     idx = torch.device(device).index
     if idx is None:

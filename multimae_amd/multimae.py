@@ -207,7 +207,7 @@ class MultiMAE(nn.Module):
         def decode(d):
             return self.output_adapters[d](encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep,
                                            ids_restore=ids_restore, fp32_output=d in fp32_output_adapters)
-        if Fn.DECODER_STREAMS and encoder_tokens.is_cuda and len(self.output_adapters) > 1:
+        if Fn.decoder_streams_enabled() and encoder_tokens.is_cuda and len(self.output_adapters) > 1:
             # one stream per decoder (they are independent until the losses); same kernels, same order per decoder, so the
             # results do not change
             main = torch.cuda.current_stream(encoder_tokens.device)

@@ -25,7 +25,8 @@ def init_distributed_mode(backend: str = "nccl"):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    single = os.environ.get("MMAE_DP_SINGLE_RANK") == "1"  # rehearsal: a one-rank group still runs every collective
+    if (world > 1 or single) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
