@@ -54,11 +54,18 @@ def split_decay(model: torch.nn.Module):
 
 
 class FlatParams:
-    """Moves the trainable parameters of `model` into one flat fp32 buffer (and their .grad into another)."""
+    """Moves the trainable parameters of `model` into one flat fp32 buffer (and their .grad into another), laid out in
+    the order backward completes their gradients so that contiguous buckets fill front to back."""
 
     def __init__(self, model: torch.nn.Module):
         decay, no_decay = split_decay(model)
-        decay, no_decay = decay[::-1], no_decay[::-1]
+
+        def backward_order(named):
+            # reverse registration order within a module group; groups in the order backward reaches them: the output
+            # adapters (registered before the encoder in MultiMAE, run after it), the encoder, the input side
+            rank = lambda name: 0 if name.startswith("output_adapters.") else (2 if name.startswith("input_adapters.") or "global_tokens" in name else 1)
+            return sorted(named[::-1], key=lambda np_: rank(np_[0]))
+        decay, no_decay = backward_order(decay), backward_order(no_decay)
         self.named = decay + no_decay
         dev = self.named[0][1].device
 
@@ -131,14 +138,25 @@ class GradBuckets:
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         cap = int(bucket_mb * (1 << 20) / 4)
+        # The all-reduce of the bucket that completes last cannot hide under backward, so the buckets taper towards the
+        # end of the (large) decayed region: the last one holds about cap / 4, the one before it cap / 2.
+        ends = [o + (p.numel() + 7) // 8 * 8 for (_, p), o in zip(flat.named, flat.offsets)]
+        taper = {}  # first element offset -> capacity, for the two tail buckets
+        left = flat.n_decay
+        for frac in (4, 2):
+            if left > 2 * cap:
+                taper[left - cap // frac] = cap // frac
+                left -= cap // frac
         self.buckets: List[List[int]] = []   # [start, end, n_params]
         self.bucket_of = {}
-        cur = None
+        cur, cur_cap = None, cap
         for i, ((_, p), o) in enumerate(zip(flat.named, flat.offsets)):
-            end = o + (p.numel() + 7) // 8 * 8
+            end = ends[i]
             boundary = (o == flat.n_decay)  # never mix the two regions
-            if cur is None or boundary or end - cur[0] > cap:
+            start_tail = next((t for t in taper if o <= t < end), None) if o < flat.n_decay else None
+            if cur is None or boundary or end - cur[0] > cur_cap or (start_tail is not None and cur[0] < start_tail - (end - o)):
                 cur = [o, end, 0]
+                cur_cap = taper.pop(start_tail) if start_tail is not None else cap
                 self.buckets.append(cur)
             cur[1] = end
             cur[2] += 1

@@ -25,7 +25,7 @@ if __name__ == "__main__":
     M = 25344
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     shapes_nt = [] if only in ("tn", "attn") else [("qkv", M, 2304, 768, 0), ("proj+res", M, 768, 768, 2), ("fc1+gelu", M, 3072, 768, 1), ("fc2+res", M, 768, 3072, 2),
-                 ("dgelu", M, 3072, 768, 3), ("dLN fc1", M, 768, 3072, 0), ("dec fc1", 50176, 1024, 256, 1), ("dec qkv", 50176, 768, 256, 0),
+                 ("dgelu", M, 3072, 768, 3), ("dLN fc1", M, 768, 3072, 0), ("dA qkv", M, 768, 2304, 0), ("dA proj", M, 768, 768, 0), ("dec fc1", 50176, 1024, 256, 1), ("dec qkv", 50176, 768, 256, 0),
                  ("dec fc2", 50176, 256, 1024, 2), ("pctx", M, 256, 768, 0)]
     for name, m, n, k, epi in shapes_nt:
         a, w = r(m, k), r(n, k)
