@@ -474,17 +474,22 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
         constexpr int s = decltype(slot_c)::value;
         int m0, n0;
         tile_origin(t, m0, n0);
+        // the lane's row terms are recomputed from an opaque copy of the lane id at every tile change: kept across the main
+        // loop they cost registers the loop does not have, and a spilled one comes back through a scratch load whose
+        // wait drains the LDS-DMA in flight
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int r = (j * 8 + wave) * 8 + (lane >> 3);
+            const int r = (j * 8 + wave) * 8 + (ln >> 3);
             if (s == 0 || s == 3) {
                 int g = m0 + (HALF ? r : (r >> 6) * 128 + (s == 3 ? 64 : 0) + (r & 63));
                 g = g < p.M ? g : p.M - 1;
-                src[s][j] = p.A + (long)g * p.lda + (((lane & 7) ^ ((r >> 1) & 7)) << 3);
+                src[s][j] = p.A + (long)g * p.lda + (((ln & 7) ^ ((r >> 1) & 7)) << 3);
             } else {
                 int g = n0 + (r >> 5) * 64 + (s == 2 ? 32 : 0) + (r & 31);
                 g = g < p.N ? g : p.N - 1;
-                src[s][j] = p.W + (long)g * p.ldw + (((lane & 7) ^ (((r >> 1) & 1) | (((r >> 3) & 3) << 1))) << 3);
+                src[s][j] = p.W + (long)g * p.ldw + (((ln & 7) ^ (((r >> 1) & 1) | (((r >> 3) & 3) << 1))) << 3);
             }
         }
     };
