@@ -49,15 +49,31 @@ struct GemmNT {
 template <int EPI, bool FULL = false, bool BREG = false>
 __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&acc)[4][4], int mw, int nw, int fr, int fq,
                                                 const float* bias_regs = nullptr, const bf16x8 (*h_regs)[2] = nullptr) {
-    // Epilogue inputs (residual / saved pre-activation) are fetched for the whole 64x64 block before anything is stored:
+    // Epilogue inputs (saved pre-activation) are fetched for the whole 64x64 block before anything is stored:
     // a load issued after a store has to wait for that store as well (one in-order counter), which would serialise
     // sixteen memory round trips.
-    constexpr int MB = EPI == EPI_RESID ? 2 : 4;  // fragment rows per batch (register budget: 16 / 8 registers per row)
-    f32x4 res[EPI == EPI_RESID ? MB : 1][2][2];
+    // The residual rows run one fragment row ahead of the stores instead (two buffers of 16 registers): the wait for row
+    // mi + 1 then leaves the stores of row mi in flight, where a batch fetched after the stores would wait for them too.
+    constexpr int MB = EPI == EPI_RESID ? 1 : 4;  // fragment rows per batch (register budget: 16 / 8 registers per row)
+    f32x4 res[EPI == EPI_RESID ? 2 : 1][2][2];
     bf16x8 hsv[EPI == EPI_DGELU ? MB : 1][2];
+    auto load_res = [&](int mi_) {
+        int m = mw + mi_ * 16 + fr;
+        m = m < p.M ? m : p.M - 1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int n = nw + 32 * u + 8 * fq;
+            n = n < p.N ? n : p.N - 8;
+            const float* rp = (const float*)p.aux + (long)m * p.ldaux + n;
+            res[EPI == EPI_RESID ? (mi_ & 1) : 0][u][0] = *(const f32x4*)rp;
+            res[EPI == EPI_RESID ? (mi_ & 1) : 0][u][1] = *(const f32x4*)(rp + 4);
+        }
+    };
+    if (EPI == EPI_RESID) load_res(0);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-        if ((EPI == EPI_RESID || (EPI == EPI_DGELU && !h_regs)) && mi % MB == 0) {
+        if (EPI == EPI_RESID && mi + 1 < 4) load_res(mi + 1);
+        if (EPI == EPI_DGELU && !h_regs && mi % MB == 0) {
 #pragma unroll
             for (int mj = 0; mj < MB; ++mj) {
                 int m = mw + (mi + mj) * 16 + fr;
@@ -66,13 +82,7 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
                 for (int u = 0; u < 2; ++u) {
                     int n = nw + 32 * u + 8 * fq;
                     n = n < p.N ? n : p.N - 8;
-                    if (EPI == EPI_RESID) {
-                        const float* rp = (const float*)p.aux + (long)m * p.ldaux + n;
-                        res[EPI == EPI_RESID ? mj : 0][u][0] = *(const f32x4*)rp;
-                        res[EPI == EPI_RESID ? mj : 0][u][1] = *(const f32x4*)(rp + 4);
-                    } else {
-                        hsv[EPI == EPI_DGELU ? mj : 0][u] = *(const bf16x8*)((const bf16*)p.aux + (long)m * p.ldaux + n);
-                    }
+                    hsv[EPI == EPI_DGELU ? mj : 0][u] = *(const bf16x8*)((const bf16*)p.aux + (long)m * p.ldaux + n);
                 }
             }
         }
@@ -124,7 +134,7 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
                 *(bf16x8*)((bf16*)p.out + orow * p.ldo + n) = h;
                 *(bf16x8*)((bf16*)p.out2 + orow * p.ldo + n) = g;
             } else if (EPI == EPI_RESID) {
-                const f32x4 r0 = res[EPI == EPI_RESID ? mi % MB : 0][u][0], r1 = res[EPI == EPI_RESID ? mi % MB : 0][u][1];
+                const f32x4 r0 = res[EPI == EPI_RESID ? (mi & 1) : 0][u][0], r1 = res[EPI == EPI_RESID ? (mi & 1) : 0][u][1];
                 float* op = (float*)p.out + orow * p.ldo + n;
                 *(f32x4*)op = (f32x4){r0[0] + v[0], r0[1] + v[1], r0[2] + v[2], r0[3] + v[3]};
                 *(f32x4*)(op + 4) = (f32x4){r1[0] + v[4], r1[1] + v[5], r1[2] + v[6], r1[3] + v[7]};
