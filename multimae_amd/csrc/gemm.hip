@@ -69,6 +69,23 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
             res[EPI == EPI_RESID ? (mi_ & 1) : 0][u][1] = *(const f32x4*)(rp + 4);
         }
     };
+    // the lane's 16 bias values once, ahead of every store (fetched between stores they would wait for those stores)
+    constexpr bool USES_BIAS = EPI != EPI_DGELU && EPI != EPI_TOKENS;
+    float bl[16];
+    if (USES_BIAS && !BREG) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bl[e] = 0.f;
+        if (p.bias) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int n = nw + 32 * u + 8 * fq;
+                n = n < p.N ? n : p.N - 8;
+                const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bl[8 * u + e] = b0[e]; bl[8 * u + 4 + e] = b1[e]; }
+            }
+        }
+    }
     if (EPI == EPI_RESID) load_res(0);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
@@ -108,14 +125,15 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = acc[2 * u][mi][e]; v[4 + e] = acc[2 * u + 1][mi][e]; }
-            if (EPI != EPI_DGELU && EPI != EPI_TOKENS && p.bias) {
+            if (USES_BIAS) {
                 if (BREG) {
+                    if (p.bias) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += bias_regs[8 * u + e];
+                        for (int e = 0; e < 8; ++e) v[e] += bias_regs[8 * u + e];
+                    }
                 } else {
-                    const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                    for (int e = 0; e < 8; ++e) v[e] += bl[8 * u + e];
                 }
             }
             if (EPI == EPI_BF16) {
