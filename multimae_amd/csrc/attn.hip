@@ -412,6 +412,10 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, 
     const int tail = p.kv_len - (nkt - 1) * 32;
 
     for (int item = wave; item < nqt + nkt; item += NW) {
+        // lane-derived indices are rebuilt from an opaque copy per item: carried across the items they are spilled
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int r = ln & 31, h2 = ln >> 5, lane = ln;
         if (item < nqt) {
             // ---- dQ of a 32-query block (see attn_bwd_dq_kernel) ----
             const int qrow = item * 32 + r;
