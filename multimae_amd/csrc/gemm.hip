@@ -1312,12 +1312,16 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab, i
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
     for (long i = tid; i < n4; i += nth) {
         f32x4 s = accumulate ? ((const f32x4*)out)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        // unrolled so that eight slab loads are in flight per thread (a small output with many splits is otherwise one
+        // dependent round trip per split); the additions keep their order
+#pragma unroll 8
         for (int k = 0; k < nsplit; ++k) s += ((const f32x4*)(slabs + k * slab))[i];
         ((f32x4*)out)[i] = s;
     }
     if (cout) {
         for (long i = tid; i < n_cols; i += nth) {
             float s = c_accumulate ? cout[i] : 0.f;
+#pragma unroll 8
             for (int k = 0; k < nsplit; ++k) s += cslabs[(long)k * n_cols + i];
             cout[i] = s;
         }
