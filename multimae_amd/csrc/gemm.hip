@@ -1449,6 +1449,7 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int chunks, 
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= N) return;
     float t = accumulate ? out[c] : 0.f;
+#pragma unroll 8
     for (int k = 0; k < chunks; ++k) t += part[(long)k * N + c];
     out[c] = t;
 }

@@ -140,6 +140,7 @@ __global__ void loss_final_kernel(LossArgs a) {
         const float nm = a.nmask[b];
         if (nm > 0.f) {
             float s = 0.f;
+#pragma unroll 8
             for (int i = 0; i < a.nh; ++i) s += a.perr[(long)b * a.nh + i];
             tot += s / ((float)(a.P * a.P) * nm);
             cnt += 1.f;
@@ -253,6 +254,7 @@ __global__ void ce_final_kernel(CeArgs a) {
         const float nm = a.nmask[b];
         if (nm > 0.f) {
             float s = 0.f;
+#pragma unroll 8
             for (int i = 0; i < a.nblk; ++i) s += a.perr[(long)b * a.nblk + i];
             tot += s / ((float)(a.P * a.P) * nm);
             cnt += 1.f;

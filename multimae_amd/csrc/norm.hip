@@ -131,8 +131,17 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     float t = 0.f;
-    if (c < 2 * dim)
-        for (int b = rg; b < nblocks; b += 32) t += part[(long)b * 2 * dim + c];
+    if (c < 2 * dim) {
+        int b = rg;
+        for (; b + 7 * 32 < nblocks; b += 8 * 32) {  // eight loads in flight, additions in order
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = part[(long)(b + j * 32) * 2 * dim + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += v[j];
+        }
+        for (; b < nblocks; b += 32) t += part[(long)b * 2 * dim + c];
+    }
     red[rg][cl] = t;
     __syncthreads();
     if (rg == 0 && c < 2 * dim) {

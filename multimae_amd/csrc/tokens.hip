@@ -140,6 +140,7 @@ __global__ void class_emb_bwd_kernel(ClsBwdArgs a) {
     float* out = a.part + (long)blockIdx.x * tsize;
     for (int i = threadIdx.x; i < tsize; i += nthr) {
         float s = 0.f;
+#pragma unroll 8
         for (int q = 0; q < a.G; ++q) s += tab[(long)q * tsize + i];
         out[i] = s;
     }
@@ -148,6 +149,7 @@ __global__ void class_emb_reduce_kernel(const float* __restrict__ part, int nblo
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
+#pragma unroll 8
     for (int b = 0; b < nblocks; ++b) s += part[(long)b * n + i];
     d_emb[i] = accumulate ? d_emb[i] + s : s;
 }
@@ -253,6 +255,7 @@ __global__ void embed_bwd_kernel(const float* __restrict__ dx, int B, int k, int
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)G * dim; i += (long)gridDim.x * blockDim.x) {
         const int d = (int)(i % dim), gi = (int)(i / dim);
         float s = 0.f;
+#pragma unroll 8
         for (int b = 0; b < B; ++b) s += dx[((long)b * seq + k + gi) * dim + d];
         d_global[i] = s;
     }
@@ -360,15 +363,28 @@ __global__ __launch_bounds__(256) void decoder_assemble_bwd_kernel(AsmBwdArgs a)
         if (pl < PL) {
             const int p0 = slot < a.T ? slot * a.ntok : 0;
             const int p1 = slot < a.T ? p0 + a.ntok : a.total;
-            for (int pos = p0 + pl; pos < p1; pos += PL) {
-                const int r = a.ids_restore[(long)b * a.total + pos];
-                const bool in_q = pos >= a.q_start && pos < a.q_start + a.q_len;
-                if (slot < a.T) {
-                    if (in_q) s += ((const f32x4*)(a.dq + ((long)b * a.q_len + pos - a.q_start) * a.Dd))[c];
-                    if (r < a.k) s += ((const f32x4*)(a.dc + ((long)b * seq + r) * a.Dd))[c];
-                } else if (in_q && r >= a.k) {
-                    s += ((const f32x4*)(a.dq + ((long)b * a.q_len + pos - a.q_start) * a.Dd))[c];
+            // four positions per trip: their indices first, then all their rows, then the additions in position order
+            // (one position per trip is a chain of two dependent loads per addition)
+            for (int pos0 = p0 + pl; pos0 < p1; pos0 += 4 * PL) {
+                int r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pos = pos0 + j * PL;
+                    r[j] = pos < p1 ? a.ids_restore[(long)b * a.total + pos] : -1;
                 }
+                f32x4 vq[4], vc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pos = pos0 + j * PL;
+                    const bool live = pos < p1;
+                    const bool in_q = live && pos >= a.q_start && pos < a.q_start + a.q_len;
+                    const bool take_q = in_q && (slot < a.T || r[j] >= a.k);
+                    const bool take_c = live && slot < a.T && r[j] < a.k;
+                    vq[j] = take_q ? ((const f32x4*)(a.dq + ((long)b * a.q_len + pos - a.q_start) * a.Dd))[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    vc[j] = take_c ? ((const f32x4*)(a.dc + ((long)b * seq + r[j]) * a.Dd))[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s += vq[j]; s += vc[j]; }
             }
         }
         __syncthreads();
@@ -387,7 +403,17 @@ __global__ void decoder_assemble_reduce_kernel(AsmRedArgs a) {
     if (i >= (a.T + 1) * a.Dd) return;
     const int slot = i / a.Dd, d = i - slot * a.Dd;
     float s = 0.f;
-    for (int b = 0; b < a.B; ++b) s += a.part[((long)b * (a.T + 1) + slot) * a.Dd + d];
+    const float* __restrict__ part = a.part + (long)slot * a.Dd + d;
+    const long stride = (long)(a.T + 1) * a.Dd;
+    int b = 0;
+    for (; b + 16 <= a.B; b += 16) {  // sixteen loads in flight, additions in order
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = part[(b + j) * stride];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += v[j];
+    }
+    for (; b < a.B; ++b) s += part[b * stride];
     float* dst = slot < a.T ? a.d_task[slot] : a.d_mask_token;
     if (dst) dst[d] = a.accumulate ? dst[d] + s : s;
 }
