@@ -337,7 +337,7 @@ struct AsmBwdArgs {
     int B, k, G, total, q_start, q_len, Dd, T, ntok;
     bf16* d_ctx; float* part;  // part[b][T+1][Dd]
 };
-__global__ __launch_bounds__(256) void decoder_assemble_bwd_kernel(AsmBwdArgs a) {
+__global__ __launch_bounds__(1024) void decoder_assemble_bwd_kernel(AsmBwdArgs a) {
     const int b = blockIdx.x;
     const int seq = a.k + a.G;
     const int nv = a.Dd / 4;
@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256) void decoder_assemble_bwd_kernel(AsmBwdArgs a)
     }
     // partial sums over positions: slot t < T collects d_emb of task t, slot T the mask token.
     // threads are laid out as (column group c, position lane pl); each walks positions pl, pl+PL, ...
-    __shared__ float red[256 * 4];
-    const int PL = blockDim.x / nv;  // position lanes (Dd=256 -> nv=64 -> 4)
+    __shared__ float red[1024 * 4];
+    const int PL = blockDim.x / nv;  // position lanes (Dd=256 -> nv=64 -> 16): one workgroup per sample, so many lanes
     const int c = threadIdx.x % nv, pl = threadIdx.x / nv;
     for (int slot = 0; slot <= a.T; ++slot) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -431,7 +431,7 @@ extern "C" int mmae_decoder_assemble_bwd(const float* d_queries, const float* d_
     if (B == 0) return MMAE_OK;
     AsmBwdArgs a = {d_queries, d_context, ids_keep_i32, ids_restore_i32, B, k, G, T * ntok, q_start, q_len, Dd, T, ntok,
                     (bf16*)d_ctx_bf16, (float*)workspace};
-    hipLaunchKernelGGL(decoder_assemble_bwd_kernel, dim3(B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(decoder_assemble_bwd_kernel, dim3(B), dim3(1024), 0, stream, a);
     MMAE_CHECK_LAUNCH("decoder_assemble_bwd");
     AsmRedArgs r = {};
     r.part = (const float*)workspace; r.B = B; r.T = T; r.Dd = Dd; r.d_mask_token = d_mask_token; r.accumulate = 0;
