@@ -66,12 +66,19 @@ __global__ void loss_main_kernel(LossArgs a) {
         }
         __syncthreads();
     };
-    if (tid == 0) {
-        float nv = 0.f;
-        for (int i = 0; i < a.B; ++i) nv += a.nmask[i] > 0.f ? 1.f : 0.f;
-        s_nvalid = nv;
+    {   // samples with at least one masked token: counted by all threads (one thread walking the batch was most of this
+        // kernel's time), combined by a tree; the terms are small integers, so the order does not matter
+        float nvp = 0.f;
+        for (int i = tid; i < a.B; i += nthreads) nvp += a.nmask[i] > 0.f ? 1.f : 0.f;
+        s_part[tid] = nvp;
+        __syncthreads();
+        for (int off = 512; off > 0; off >>= 1) {
+            if (tid < off && tid + off < nthreads) s_part[tid] += s_part[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) s_nvalid = s_part[0];
+        __syncthreads();
     }
-    __syncthreads();
 
     auto off_of = [&](int r) {
         const int c = r / a.P, ph = r - c * a.P;
@@ -203,10 +210,11 @@ __global__ __launch_bounds__(256) void ce_main_kernel(CeArgs a) {
     const long HW = (long)a.H * a.W;
     const long px = (long)blockIdx.x * 256 + threadIdx.x;
     const bool live = px < HW;
-    if (threadIdx.x == 0) {
-        float nv = 0.f;
-        for (int i = 0; i < a.B; ++i) nv += a.nmask[i] > 0.f ? 1.f : 0.f;
-        s_nvalid = nv;
+    {   // samples with at least one masked token (small integers: any order)
+        float nvp = 0.f;
+        for (int i = threadIdx.x; i < a.B; i += 256) nvp += a.nmask[i] > 0.f ? 1.f : 0.f;
+        nvp = block_sum(nvp, red);
+        if (threadIdx.x == 0) s_nvalid = nvp;
     }
     __syncthreads();
     float e = 0.f;
