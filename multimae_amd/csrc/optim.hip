@@ -182,6 +182,34 @@ __global__ __launch_bounds__(256) void transpose_multi_kernel(const bf16* __rest
     const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
     const bf16* s = src + d.x;
     bf16* o = dst + d.x;
+    if ((rows & 7) == 0 && (cols & 7) == 0) {
+        // 16-byte global accesses: a thread moves 8 elements of a row in, 8 elements of a column out (tensor offsets are
+        // multiples of 8 elements, so both sides are aligned)
+        for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+            const int rr = i >> 3, ch = i & 7;
+            const int r = r0 + rr, c = c0 + ch * 8;
+            bf16x8 v;
+            if (r < rows && c < cols) v = *(const bf16x8*)(s + (long)r * cols + c);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tile[rr][ch * 8 + e] = v[e];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+            const int cc = i >> 3, ch = i & 7;
+            const int c = c0 + cc, r = r0 + ch * 8;
+            if (c < cols && r < rows) {
+                bf16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tile[ch * 8 + e][cc];
+                *(bf16x8*)(o + (long)c * rows + r) = v;
+            }
+        }
+        return;
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
         const int r = r0 + i, c = c0 + tx;

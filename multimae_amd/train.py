@@ -193,12 +193,19 @@ class GradBuckets:
         if buf.is_cuda:  # kernels of several decoder streams may have written into this bucket
             Fn.join_aux_streams(buf.device, reset=False)
         side = Fn.side_stream_pending(buf.device) if buf.is_cuda else None
+        # gloo stages device tensors through the host; several of those in flight on one device have stalled (seen with two
+        # ranks sharing a GPU), so each is finished before the next is issued.  RCCL stays asynchronous.
+        serial = buf.is_cuda and dist.get_backend(self.group) == "gloo"
         if side is None:
-            self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            return
-        side.wait_stream(torch.cuda.current_stream(buf.device))
-        with torch.cuda.stream(side):
-            self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            side.wait_stream(torch.cuda.current_stream(buf.device))
+            with torch.cuda.stream(side):
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if serial:
+            work.wait()
+        else:
+            self.works.append(work)
 
     def finish(self):
         """Call after backward: launches any bucket whose parameters received no gradient, waits for all."""

@@ -349,7 +349,7 @@ def test_masked_loss_full_size_vs_oracle(ops, C):
 
 def test_transpose_multi_matches_torch(ops):
     torch.manual_seed(3)
-    shapes = [(768, 2304), (100, 36), (64, 64), (8, 264), (3072, 768)]
+    shapes = [(768, 2304), (100, 36), (64, 64), (8, 264), (3072, 768), (72, 40)]
     offs, off, rows, tiles = [], 0, [], 0
     for n, k in shapes:
         offs.append(off)
