@@ -17,8 +17,17 @@ def _L():
     return _lib.load()
 
 
+def _raw_stream(device_index: int = -1) -> int:
+    """Handle of the current HIP stream of the device (the current device for -1).  torch.cuda.current_stream() builds a
+    Stream object through several Python layers (about 9 us a call, several hundred calls a step); the C accessor is the
+    same lookup without them."""
+    if device_index < 0:
+        device_index = torch._C._cuda_getDevice()
+    return torch._C._cuda_getCurrentRawStream(device_index)
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_raw_stream())
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -82,7 +91,10 @@ _WS = {}
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only scratch buffer per (device, stream): kernels on one stream run in order, so they can share it."""
-    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+    if idx is None:
+        idx = torch._C._cuda_getDevice()
+    key = (idx, _raw_stream(idx))
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
