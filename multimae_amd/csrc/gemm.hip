@@ -46,7 +46,9 @@ struct GemmNT {
 // FULL: the caller guarantees the 64x64 block lies inside the matrix; the stores then carry no per-lane condition, so
 // the epilogue is straight-line code (at every branch join the compiler waits for all outstanding memory operations,
 // the stores just issued included, before touching a loaded value again).
-template <int EPI, bool FULL = false, bool BREG = false>
+// RALL: the whole residual block (64 registers) is fetched before the first store, for callers with registers to spare
+// (one tile per CU in flight: the epilogue is then bound by the latency of each row's round trip).
+template <int EPI, bool FULL = false, bool BREG = false, bool RALL = false>
 __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&acc)[4][4], int mw, int nw, int fr, int fq,
                                                 const float* bias_regs = nullptr, const bf16x8 (*h_regs)[2] = nullptr) {
     // Epilogue inputs (saved pre-activation) are fetched for the whole 64x64 block before anything is stored:
@@ -55,7 +57,8 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
     // The residual rows run one fragment row ahead of the stores instead (two buffers of 16 registers): the wait for row
     // mi + 1 then leaves the stores of row mi in flight, where a batch fetched after the stores would wait for them too.
     constexpr int MB = EPI == EPI_RESID ? 1 : 4;  // fragment rows per batch (register budget: 16 / 8 registers per row)
-    f32x4 res[EPI == EPI_RESID ? 2 : 1][2][2];
+    constexpr int RBUF = EPI == EPI_RESID ? (RALL ? 4 : 2) : 1;
+    f32x4 res[RBUF][2][2];
     bf16x8 hsv[EPI == EPI_DGELU ? MB : 1][2];
     auto load_res = [&](int mi_) {
         int m = mw + mi_ * 16 + fr;
@@ -65,8 +68,8 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
             int n = nw + 32 * u + 8 * fq;
             n = n < p.N ? n : p.N - 8;
             const float* rp = (const float*)p.aux + (long)m * p.ldaux + n;
-            res[EPI == EPI_RESID ? (mi_ & 1) : 0][u][0] = *(const f32x4*)rp;
-            res[EPI == EPI_RESID ? (mi_ & 1) : 0][u][1] = *(const f32x4*)(rp + 4);
+            res[mi_ & (RBUF - 1)][u][0] = *(const f32x4*)rp;
+            res[mi_ & (RBUF - 1)][u][1] = *(const f32x4*)(rp + 4);
         }
     };
     // the lane's 16 bias values once, ahead of every store (fetched between stores they would wait for those stores)
@@ -86,10 +89,13 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
             }
         }
     }
-    if (EPI == EPI_RESID) load_res(0);
+    if (EPI == EPI_RESID) {
+        load_res(0);
+        if (RALL) { load_res(1); load_res(2); load_res(3); }
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-        if (EPI == EPI_RESID && mi + 1 < 4) load_res(mi + 1);
+        if (EPI == EPI_RESID && !RALL && mi + 1 < 4) load_res(mi + 1);
         if (EPI == EPI_DGELU && !h_regs && mi % MB == 0) {
 #pragma unroll
             for (int mj = 0; mj < MB; ++mj) {
@@ -152,7 +158,7 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
                 *(bf16x8*)((bf16*)p.out + orow * p.ldo + n) = h;
                 *(bf16x8*)((bf16*)p.out2 + orow * p.ldo + n) = g;
             } else if (EPI == EPI_RESID) {
-                const f32x4 r0 = res[EPI == EPI_RESID ? (mi & 1) : 0][u][0], r1 = res[EPI == EPI_RESID ? (mi & 1) : 0][u][1];
+                const f32x4 r0 = res[mi & (RBUF - 1)][u][0], r1 = res[mi & (RBUF - 1)][u][1];
                 float* op = (float*)p.out + orow * p.ldo + n;
                 *(f32x4*)op = (f32x4){r0[0] + v[0], r0[1] + v[1], r0[2] + v[2], r0[3] + v[3]};
                 *(f32x4*)(op + 4) = (f32x4){r1[0] + v[4], r1[1] + v[5], r1[2] + v[6], r1[3] + v[7]};
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
         cur ^= 1;
     }
 
-    if (m0 + BM <= p.M && n0 + BN <= p.N) store_wave_tile<EPI, true>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
+    if (m0 + BM <= p.M && n0 + BN <= p.N) store_wave_tile<EPI, true, false, true>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
     else store_wave_tile<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
 }
 
@@ -724,7 +730,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
                     if (!HALF) store_wave_tile<EPI, false, true>(p, acc[NH2 - 1], rb + 64, n0 + wn * 64, fr, fq, bv, hs[NH2 - 1]);
                 }
             } else if (full) {
-                store_wave_tile<EPI, true, true>(p, acc[0], rb, n0 + wn * 64, fr, fq, bv);
+                store_wave_tile<EPI, true, true, HALF>(p, acc[0], rb, n0 + wn * 64, fr, fq, bv);
                 if (!HALF) store_wave_tile<EPI, true, true>(p, acc[NH2 - 1], rb + 64, n0 + wn * 64, fr, fq, bv);
             } else {
                 store_wave_tile<EPI, false, true>(p, acc[0], rb, n0 + wn * 64, fr, fq, bv);
