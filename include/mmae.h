@@ -109,6 +109,9 @@ int mmae_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma, 
                        const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta, int accumulate,
                        int rows, int dim, void* workspace, size_t workspace_bytes, mmae_stream_t stream);
 
+/* Kernel choice for mmae_layernorm_bwd: 0 = several rows per wave and pass where dim is 256, 768 or 1024 (default),
+ * 1 = the generic one-row kernel everywhere.  Process-wide; for tests and tuning. */
+int mmae_layernorm_bwd_set_variant(int variant);
 int mmae_layernorm_param_reduce(const void* workspace, size_t workspace_bytes, int rows, int dim, float* dgamma, float* dbeta,
                                 int accumulate, mmae_stream_t stream);
 

@@ -123,6 +123,109 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
     }
 }
 
+// Backward for dim == 256 * NV, R rows per wave and pass.  Every global load of the R rows (dy, x, the incoming residual
+// gradient, the row statistics) is issued before the first reduction, so a wave keeps R * 12 * dim bytes in flight: with
+// one row per pass the loads of a row wait behind the two wave reductions of the previous one and the kernel runs on
+// latency, not bandwidth.  Measured cold on MI355X: 768-wide rows 76 -> 54 us (one row per pass is enough once the loads
+// lead), 256-wide decoder rows 59 -> 34 us with two rows per pass; more rows or more blocks change nothing (4.4 TB/s,
+// the rate the forward kernel streams at).  Rows past the end are clamped for the loads and masked after.
+template <int NV, int R>
+__global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                                 float* __restrict__ dx, bf16* __restrict__ dxb,
+                                                                 float* __restrict__ part, int rows) {
+    __shared__ float red[4][2][64 * 4];
+    constexpr int dim = 256 * NV;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    f32x4 dg[NV], db[NV], gm[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        dg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        db[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        gm[i] = ((const f32x4*)gamma)[lane + i * 64];
+    }
+    const int stride = gridDim.x * 4 * R;
+    for (int row0 = (blockIdx.x * 4 + w) * R; row0 < rows; row0 += stride) {
+        bf16x4 d4[R][NV];
+        f32x4 xv[R][NV], dr[R][NV];
+        float mu[R], rs[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r < rows ? row0 + r : rows - 1;
+            mu[r] = mean[row];
+            rs[r] = rstd[row];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + i * 64;
+                d4[r][i] = *(const bf16x4*)(dy + (long)row * dim + c * 4);
+                xv[r][i] = ((const f32x4*)(x + (long)row * dim))[c];
+                if (dres) dr[r][i] = ((const f32x4*)(dres + (long)row * dim))[c];
+            }
+        }
+        float s1[R], s2[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool live = row0 + r < rows;  // wave-uniform
+            s1[r] = s2[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const f32x4 d = {(float)d4[r][i][0], (float)d4[r][i][1], (float)d4[r][i][2], (float)d4[r][i][3]};
+                const f32x4 xh = (xv[r][i] - mu[r]) * rs[r];
+                const f32x4 g = d * gm[i];
+                if (live) {
+                    dg[i] += d * xh;
+                    db[i] += d;
+                }
+                s1[r] += g[0] + g[1] + g[2] + g[3];
+                const f32x4 t = g * xh;
+                s2[r] += t[0] + t[1] + t[2] + t[3];
+                xv[r][i] = xh;  // keep x-hat and gamma * dy in place of the loaded values
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)  // the 2 R reductions side by side
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                s1[r] += __shfl_xor(s1[r], o, 64);
+                s2[r] += __shfl_xor(s2[r], o, 64);
+            }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (row0 + r >= rows) break;
+            const long base = (long)(row0 + r) * dim;
+            const float c1 = s1[r] / dim, c2 = s2[r] / dim;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + i * 64;
+                const f32x4 d = {(float)d4[r][i][0], (float)d4[r][i][1], (float)d4[r][i][2], (float)d4[r][i][3]};
+                f32x4 o = (d * gm[i] - c1 - xv[r][i] * c2) * rs[r];
+                if (dres) o += dr[r][i];
+                ((f32x4*)(dx + base))[c] = o;
+                if (dxb) {
+                    bf16x4 ob = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+                    *(bf16x4*)(dxb + base + c * 4) = ob;
+                }
+            }
+        }
+    }
+    float* prow = part + (long)blockIdx.x * 2 * dim;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        __syncthreads();
+        *(f32x4*)&red[w][0][lane * 4] = dg[i];
+        *(f32x4*)&red[w][1][lane * 4] = db[i];
+        __syncthreads();
+        if (w < 2) {
+            f32x4 t = *(f32x4*)&red[0][w][lane * 4];
+            t += *(f32x4*)&red[1][w][lane * 4];
+            t += *(f32x4*)&red[2][w][lane * 4];
+            t += *(f32x4*)&red[3][w][lane * 4];
+            *(f32x4*)(prow + w * dim + (lane + i * 64) * 4) = t;
+        }
+    }
+}
+
 // column sums of the per-block partial rows: 32 columns x 32 row groups per block, fixed order
 __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ part, int nblocks, int dim,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -151,6 +254,14 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
         float* dst = c < dim ? dgamma + c : dbeta + (c - dim);
         *dst = accumulate ? *dst + t : t;
     }
+}
+
+// 0: the multi-row kernel where dim is 256 / 768 / 1024, 1: the generic one-row-per-pass kernel everywhere (for tests and timing)
+static int g_ln_bwd_variant = 0;
+extern "C" int mmae_layernorm_bwd_set_variant(int v) {
+    MMAE_REQUIRE(v == 0 || v == 1, MMAE_EINVAL, "layernorm_bwd_set_variant: %d is not 0 or 1", v);
+    g_ln_bwd_variant = v;
+    return MMAE_OK;
 }
 
 static int ln_bwd_blocks(int rows) {
@@ -182,8 +293,16 @@ extern "C" int mmae_layernorm_bwd(const void* dy, const float* x, const float* g
                  "layernorm_bwd: dim=%d must be a multiple of 4 and <= %d", dim, 256 * LN_MAXV);
     MMAE_REQUIRE(workspace_bytes >= mmae_layernorm_bwd_workspace_bytes(rows, dim), MMAE_EWORKSPACE, "layernorm_bwd: workspace too small");
     const int nb = ln_bwd_blocks(rows);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const bf16*)dy, x, gamma, mean, rstd, dres, dx,
-                       (bf16*)dx_bf16, (float*)workspace, rows, dim);
+#define LN_BWD_ROWS(NV, R)                                                                                                  \
+    hipLaunchKernelGGL((layernorm_bwd_rows_kernel<NV, R>), dim3(nb), dim3(256), 0, stream, (const bf16*)dy, x, gamma, mean, rstd, \
+                       dres, dx, (bf16*)dx_bf16, (float*)workspace, rows)
+    if (g_ln_bwd_variant != 1 && dim == 256) LN_BWD_ROWS(1, 2);
+    else if (g_ln_bwd_variant != 1 && dim == 768) LN_BWD_ROWS(3, 1);
+    else if (g_ln_bwd_variant != 1 && dim == 1024) LN_BWD_ROWS(4, 1);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const bf16*)dy, x, gamma, mean, rstd, dres, dx,
+                           (bf16*)dx_bf16, (float*)workspace, rows, dim);
+#undef LN_BWD_ROWS
     MMAE_CHECK_LAUNCH("layernorm_bwd");
     if (dgamma) return mmae_layernorm_param_reduce(workspace, workspace_bytes, rows, dim, dgamma, dbeta, accumulate, stream);
     return MMAE_OK;

@@ -139,8 +139,15 @@ def test_colsum(ops):
 
 
 # ---------------------------------------------------------------------------------------------- LayerNorm
-@pytest.mark.parametrize("rows,dim", [(25344, 768), (397, 256), (50, 1024), (7, 64)])
-def test_layernorm(ops, rows, dim):
+@pytest.fixture(params=[0, 1], ids=["rows", "generic"])
+def ln_bwd_variant(request, ops):
+    ops._L().mmae_layernorm_bwd_set_variant(request.param)
+    yield request.param
+    ops._L().mmae_layernorm_bwd_set_variant(0)
+
+
+@pytest.mark.parametrize("rows,dim", [(25344, 768), (25343, 768), (397, 256), (50176, 256), (50, 1024), (7, 64), (1, 256)])
+def test_layernorm(ops, rows, dim, ln_bwd_variant):
     x = _randn(rows, dim, seed=15, dtype=torch.float32) * 2 + 0.3
     g = _randn(dim, seed=16, dtype=torch.float32) * 0.1 + 1
     b = _randn(dim, seed=17, dtype=torch.float32) * 0.1
