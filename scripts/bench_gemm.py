@@ -38,7 +38,11 @@ if __name__ == "__main__":
             t = timeit(lambda: ops.gemm_nt(epi, a, w, None if epi == 3 else bias, aux=aux))
             res.append(f"{t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
         ops._L().mmae_gemm_nt_set_variant(0)
-        print(f"gemm_nt {name:10s} M={m} N={n} K={k}: t128 {res[0]} | p128 {res[1]} | pp256 full {res[2]} | pp256 {res[3]} | auto {res[4]}")
+        # yardstick only (not a product path): the vendor library's plain bf16 product of the same shape, no epilogue
+        out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
+        t = timeit(lambda: torch.matmul(a, w.t(), out=out))
+        print(f"gemm_nt {name:10s} M={m} N={n} K={k}: t128 {res[0]} | p128 {res[1]} | pp256 full {res[2]} | pp256 {res[3]} | auto {res[4]}"
+              f" | vendor plain {t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
     if len(sys.argv) > 1 and sys.argv[1] == "nt":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tn":
@@ -53,7 +57,9 @@ if __name__ == "__main__":
             t = timeit(lambda: ops.gemm_tn(x, y, out=out, accumulate=True, colsum_out=cs, colsum_accumulate=True))
             res.append(f"{t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
         ops._L().mmae_gemm_tn_set_variant(0)
-        print(f"gemm_tn {name:10s} M={m} N={n} K={k}: t128 {res[0]} | pp256 {res[1]}")
+        o2 = torch.empty(n, k, device="cuda", dtype=torch.bfloat16)
+        t = timeit(lambda: torch.matmul(x.t(), y, out=o2))  # yardstick: vendor library, bf16 output, no column sums
+        print(f"gemm_tn {name:10s} M={m} N={n} K={k}: t128 {res[0]} | pp256 {res[1]} | vendor plain {t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
     for name, B, H, nq, nk, d in [("enc", 256, 12, 99, 99, 64), ("dec self", 256, 8, 196, 196, 32), ("dec cross", 256, 8, 196, 99, 32)]:
         if nq == nk:
             qkv = r(B * nq, 3 * H * d); q, k_, v = qkv[:, :H*d], qkv[:, H*d:2*H*d], qkv[:, 2*H*d:]
