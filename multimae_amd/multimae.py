@@ -52,6 +52,7 @@ class MultiMAE(nn.Module):
                   attn_drop=attn_drop_rate, drop_path=0.0, norm_layer=norm_layer) for _ in range(depth)])
         self._reset_parameters()
         self._last_ids_i32 = None
+        self._concentrations = {}  # (device, alphas) -> Dirichlet concentrations on the device
 
     # -- initialisation (reference: multimae/multimae.py:117-146) ------------------------------------
     def _reset_parameters(self):
@@ -109,7 +110,16 @@ class MultiMAE(nn.Module):
             if sample_tasks_uniformly:
                 p = Dirichlet(self.sample_alphas(B, len(sizes), alphas=al)).sample().to(device)
             else:
-                p = Dirichlet(torch.tensor(al, dtype=torch.float32, device=device)).sample((B,))
+                # same draw as Dirichlet(concentration).sample((B,)) (reference: multimae/multimae.py:214-216) without the
+                # per-call host->device copy of the concentrations and the distribution's argument check, each of
+                # which makes the host wait for the device once per step
+                if any(not a > 0 for a in al):
+                    raise ValueError(f"alphas must be positive, got {al}")
+                key = (str(device), tuple(float(a) for a in al))
+                conc = self._concentrations.get(key)
+                if conc is None:
+                    conc = self._concentrations[key] = torch.tensor(key[1], dtype=torch.float32, device=device)
+                p = torch._sample_dirichlet(conc.expand(B, len(sizes)))
             noise = torch.cat([torch.rand(B, n, device=device) for n in sizes], dim=1)
             noise_all = torch.rand(B, sum(sizes), device=device)
         mask, ids_keep, ids_restore, keep32, restore32 = ops.mask_generate(

@@ -580,3 +580,28 @@ def test_full_batch_step_is_the_mean_of_its_chunks():
     print({k_: f"{v:.2e}" for k_, v in errs.items()}, "worst per-tensor grads:", [(n, f"{e:.2e}") for n, e in worst])
     assert all(v < 1e-5 for v in errs.values()), errs
     assert all(e < 1e-4 for e in gerr.values()), worst
+
+
+def test_step_with_its_own_mask_draws_never_waits_for_the_device():
+    """A whole optimisation step with the model drawing its own masks (Dirichlet + uniform noise on the device), under
+    torch's synchronisation check: any call that makes the host wait for the device (.item(), a pageable host->device
+    copy, a distribution's argument check) raises.  One such wait per step drains the launch queue and leaves the device
+    idle at the start of the next step."""
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    from multimae_amd.train import PretrainStep
+    cfg = O.small_cfg()
+    x = {d: t.cuda() for d, t in G.seeded_inputs(cfg, B=4, seed=3).items()}
+    model = _build(cfg)
+    model.load_state_dict(G.perturbed_state(cfg, seed=7))
+    model.cuda()
+    step = PretrainStep(model, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05, clip_grad=1.0)
+    step(x)  # first call: allocations, cached tables
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for _ in range(2):
+            loss, _, _ = step(x)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert torch.isfinite(loss).item()
