@@ -345,7 +345,11 @@ class PretrainStep:
                                   sample_tasks_uniformly=self.uniform, fp32_output_adapters=self.fp32_out)
         task_losses = {t: fn(preds[t], batch[tgt], mask=masks.get(tgt)) for t, (fn, tgt) in self.losses.items()}
         loss = sum(task_losses.values())
-        loss.backward()
+        Fn.UNIT_LOSS_GRADS = True  # d(loss) / d(task loss) = 1 for every task
+        try:
+            loss.backward()
+        finally:
+            Fn.UNIT_LOSS_GRADS = False
         self.buckets.finish()
         Fn.join_side_stream()
         gn2 = self.opt.grad_norm_sq()  # of the summed (not yet averaged) gradients: norm = sqrt(gn2) / world
