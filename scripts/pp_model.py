@@ -6,6 +6,9 @@ import os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multimae_amd import _lib
+if os.environ.get("PP_MODEL_LIB"):  # another build of the library (A/B on one box)
+    _lib.LIB_PATH = os.path.abspath(os.environ["PP_MODEL_LIB"])
 from multimae_amd import ops
 from bench_gemm import timeit, r as rnd
 

@@ -36,7 +36,9 @@ def nt_variant(request, ops):
     ops._L().mmae_gemm_nt_set_half_tiles(1)
 
 
-@pytest.mark.parametrize("M,N,K", [(396, 2304, 768), (25344, 768, 768), (1000, 256, 256), (128, 3072, 768), (777, 768, 3072), (130, 2128, 256)])
+# the last three: several rounds of 256x256 tiles per CU (tiles dealt from the per-XCD counters) at 4, 6 and 12 k-tiles per tile
+@pytest.mark.parametrize("M,N,K", [(396, 2304, 768), (25344, 768, 768), (1000, 256, 256), (128, 3072, 768), (777, 768, 3072), (130, 2128, 256),
+                                   (50176, 1024, 256), (33000, 1280, 384), (25344, 2304, 768)])
 def test_gemm_nt_bias(ops, nt_variant, M, N, K):
     a, w = _randn(M, K, seed=1), _randn(N, K, seed=2, scale=0.05)
     bias = _randn(N, seed=3, dtype=torch.float32)
