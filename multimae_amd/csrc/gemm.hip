@@ -627,8 +627,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
 
     if (wm == 1) __builtin_amdgcn_s_barrier();  // second wave group runs one barrier behind
 
-    // Next-tile protocol, once per tile: in its first k-tile thread 0 draws from the XCD's counter; at the top of the
-    // second k-tile it converts the draw to a tile id and publishes it in LDS, and every wave reads it one phase (two
+    // Next-tile protocol, once per tile: in the first k-tile of a pair thread 0 draws from the XCD's counter; at the top of
+    // the second it converts the draw to a tile id and publishes it in LDS, and every wave reads it one phase (two
     // barriers) later.  The staging cursors move on to the next tile as soon as they have issued a tile's last load,
     // the first of them in phase 1 of k-tile nk - 3: with K >= 256 (nk >= 4) that is the phase the id is read in.
     // The draw returns into v255, named in the asm and otherwise unused by these instances (their own demand stays below
@@ -654,13 +654,17 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
         }
     };
     auto read_tile = [&]() { nxt = __builtin_amdgcn_readfirstlane(*next_lds); };
+    // The workgroups of an XCD run in step, and 32 draws from one counter at the same moment queue up behind each other
+    // in the L2 (the last waits over a microsecond, and the loads behind it with it): each workgroup draws in a k-tile
+    // pair of its own, as late as nk - 4 (the id is read one k-tile after the draw and needed in k-tile nk - 3).
+    const int draw_kt = 2 * ((blockIdx.x >> 3) % ((nk - 2) >> 1));
 
     int tile = me, kt = 0;
     while (true) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const char* buf = ppsmem + b * PP_KT_BYTES;
-            if (DEAL && kt == 0) {
+            if (DEAL && kt == draw_kt) {
                 if (b == 0) draw_tile();
                 else publish_tile();
             }
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
                 mfma_quad(acc[0], 0, wlo);
                 __builtin_amdgcn_s_barrier();
                 // ---- phase 1 ----
-                if (DEAL && kt == 0 && b == 1) read_tile();
+                if (DEAL && kt == draw_kt && b == 1) read_tile();
                 read_w(buf + 2 * PP_H_BYTES, whi);
                 stage_slot(S0{});
                 stage_slot(S1{});
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
             mfma_quad(acc[0], 0, wlo);
             __builtin_amdgcn_s_barrier();
             // ---- phase 1 ----
-            if (DEAL && kt == 0 && b == 1) read_tile();
+            if (DEAL && kt == draw_kt && b == 1) read_tile();
             read_w(buf + 2 * PP_H_BYTES, whi);
             stage_slot(S0{});
             __builtin_amdgcn_s_barrier();
