@@ -7,7 +7,6 @@
 // 16-byte global->LDS DMA into a double-buffered, XOR-swizzled LDS image.
 #include "common.h"
 #include <type_traits>
-#include <atomic>
 #include <stdlib.h>
 
 #define BM 128
@@ -462,8 +461,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 ? 2 : 2)) void gemm_nt_persist_k
 // reads and loads, the other runs its MFMA cluster.
 // Slot images: 128 rows x 128 B; slot 0 / 3 hold activation rows {wm*128 + (0|64) + 0..63}, slot 1 / 2 weight rows
 // {wn*64 + (0|32) + 0..31}; 16-byte chunk c of row r sits at c ^ swz(r) (same two swizzles as the 128x128 kernel).
-// Requires K % 128 == 0 (k-tiles come in pairs, one per LDS buffer) and K >= 256 (the id of a workgroup's next tile is
-// read in the second k-tile of a tile, the phase in which the first staging cursor of a four-k-tile tile moves on).
+// Requires K % 128 == 0 (k-tiles come in pairs, one per LDS buffer).
 // HALF: 128x256 tiles for the tail of a problem.  A workgroup owns a CU, so a last round with few tiles leaves most CUs
 // idle for a whole tile time; the launcher may instead give the last row panels to a second launch of this instance, in
 // which slot 0 holds 128 contiguous rows (64 per wave group, one 64x64 block per wave), slot 3 and the second
@@ -472,38 +470,20 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 ? 2 : 2)) void gemm_nt_persist_k
 // ------------------------------------------------------------------------------------------
 #define PP_H_BYTES 16384
 #define PP_KT_BYTES (4 * PP_H_BYTES)
-#define PP_LDS (2 * PP_KT_BYTES + 8 * 256 + 16)  // + per-wave bias slice (64 floats) + the next tile id
-// Tile queues of the launches in flight: launch number % PP_QUEUES owns 8 counters (one per XCD) and a count of finished
-// workgroups; the last workgroup of a launch to finish clears them for the launch that reuses the entry.
-#define PP_QUEUES 256
-__device__ unsigned g_pp_ctr[PP_QUEUES * 8];
-__device__ unsigned g_pp_done[PP_QUEUES];
+#define PP_LDS (2 * PP_KT_BYTES + 8 * 256)  // + per-wave bias slice (64 floats)
 
 template <int EPI, bool HALF>
-__global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_m, int tiles_n, int queue) {
+__global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char ppsmem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fq = lane >> 4, swz = fr >> 1;
-    const int ntiles = tiles_m * tiles_n, G = gridDim.x;  // G <= ntiles (launcher)
+    const int ntiles = tiles_m * tiles_n, G = gridDim.x;
+    const int me = xcd_remap(blockIdx.x, G);
     const int nk = p.K >> 6;
-    // Tiles are dealt per XCD (workgroups i, i + 8, ... share one and its L2): XCD x owns the contiguous ids
-    // [base, base + per) of every round of G tiles, the same ids a static stride of G from xcd_remap() would give it, but
-    // its workgroups draw them from a counter, first come first served, after a first tile fixed by the block id.  A
-    // workgroup owns a CU, so one that starts late (its CU was held by a kernel of another stream: a weight-gradient
-    // GEMM, a collective) would otherwise finish its fixed share late with the rest of the chip idle.
-    const int xq = blockIdx.x & 7, qn = G >> 3, qr = G & 7;
-    const int per = qn + (xq < qr ? 1 : 0);
-    const int base = xq < qr ? xq * (qn + 1) : qr * (qn + 1) + (xq - qr) * qn;
-    const int me = base + (blockIdx.x >> 3);
-    unsigned* tile_ctr = g_pp_ctr + queue * 8 + xq;
-    typedef __attribute__((address_space(3))) int lds_int;
-    lds_int* next_lds = (lds_int*)(ppsmem + 2 * PP_KT_BYTES + 8 * 256);  // LDS address space: a generic store would be a flat one with a full wait
-    // The full-tile instance with the fp32 residual epilogue has no register to spare (it spills, and the compiler does
-    // reach for v255 there): it keeps the static stride.  Its launches are single rounds (N = 768 and the decoder's
-    // N = 256), where there is nothing to deal.
-    constexpr bool DEAL = !(EPI == EPI_RESID && !HALF);
-    int nxt = DEAL ? -1 : (me + G < ntiles ? me + G : -1);  // tile after the current one, uniform; -1 = none
+    if (me >= ntiles) return;
+    const int my_tiles = (ntiles - 1 - me) / G + 1;
+    const int total_kt = my_tiles * nk;
     float* bias_lds = (float*)(ppsmem + 2 * PP_KT_BYTES) + wave * 64;
 
     auto tile_origin = [&](int t, int& m0, int& n0) {
@@ -553,13 +533,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
         char* dst = ppsmem + (s_kt[s] & 1) * PP_KT_BYTES + s * PP_H_BYTES + wave * 1024;
         glds16(src[s][0], dst);
         glds16(src[s][1], dst + 8 * 1024);
-        if (s_tile[s] >= 0) {
+        if (s_tile[s] < ntiles) {
             src[s][0] += 64; src[s][1] += 64;
             if (++s_kt[s] == nk) {
                 s_kt[s] = 0;
-                s_tile[s] = nxt;  // read in the second k-tile of the tile this cursor leaves
-                if (nxt >= 0) {
-                    set_slot(slot_c, nxt);
+                s_tile[s] += G;
+                if (s_tile[s] < ntiles) {
+                    set_slot(slot_c, s_tile[s]);
                 } else {  // end of this workgroup's stream: the run-ahead copies read the zero page (never consumed)
                     src[s][0] = src[s][1] = (const bf16*)g_zero_page;
                 }
@@ -627,47 +607,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
 
     if (wm == 1) __builtin_amdgcn_s_barrier();  // second wave group runs one barrier behind
 
-    // Next-tile protocol, once per tile: in the first k-tile of a pair thread 0 draws from the XCD's counter; at the top of
-    // the second it converts the draw to a tile id and publishes it in LDS, and every wave reads it one phase (two
-    // barriers) later.  The staging cursors move on to the next tile as soon as they have issued a tile's last load,
-    // the first of them in phase 1 of k-tile nk - 3: with K >= 256 (nk >= 4) that is the phase the id is read in.
-    // The draw returns into v255, named in the asm and otherwise unused by these instances (their own demand stays below
-    // 255 registers; tests/test_build.py checks the disassembly): a compiler-visible result would be waited for on the
-    // spot (a full drain of the loads in flight, once per tile), and a result in a compiler-allocated register of an asm
-    // statement may be copied or spilled before it has landed.  The counted vmcnt at the end of the first k-tile covers
-    // it (the draw is older than the six newest loads), so v255 is read without a wait of its own.
-    auto draw_tile = [&]() {
-        if (tid == 0) asm volatile("global_atomic_add v255, %0, %1, off sc0" : : "v"(tile_ctr), "v"(1u) : "memory", "v255");
-    };
-    auto publish_tile = [&]() {
-        // the divisor goes through an opaque scalar copy: hoisted out of the main loop, the reciprocal of the division
-        // would live in (or spill from) vector registers the loop does not have, and a reload waits for every load in flight
-        unsigned pq = (unsigned)__builtin_amdgcn_readfirstlane(per);
-        asm volatile("" : "+s"(pq));
-        if (tid == 0) {
-            unsigned drawn;
-            asm volatile("v_mov_b32 %0, v255" : "=v"(drawn));
-            const unsigned n = pq + drawn;  // the first `per` draws of the XCD are the fixed first tiles
-            const unsigned round = n / pq;
-            const unsigned t = round * (unsigned)G + (unsigned)base + (n - round * pq);
-            *next_lds = t < (unsigned)ntiles ? (int)t : -1;
-        }
-    };
-    auto read_tile = [&]() { nxt = __builtin_amdgcn_readfirstlane(*next_lds); };
-    // The workgroups of an XCD run in step, and 32 draws from one counter at the same moment queue up behind each other
-    // in the L2 (the last waits over a microsecond, and the loads behind it with it): each workgroup draws in a k-tile
-    // pair of its own, as late as nk - 4 (the id is read one k-tile after the draw and needed in k-tile nk - 3).
-    const int draw_kt = 2 * ((blockIdx.x >> 3) % ((nk - 2) >> 1));
-
     int tile = me, kt = 0;
-    while (true) {
+    for (int T = 0; T < total_kt; T += 2) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const char* buf = ppsmem + b * PP_KT_BYTES;
-            if (DEAL && kt == draw_kt) {
-                if (b == 0) draw_tile();
-                else publish_tile();
-            }
             if constexpr (HALF) {
                 // Two phases per k-tile.  Every LDS read is complete before the phase's first barrier, so a slot may be
                 // refilled in the phase after the one that reads it although the wave groups run one barrier apart:
@@ -693,7 +637,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
                 mfma_quad(acc[0], 0, wlo);
                 __builtin_amdgcn_s_barrier();
                 // ---- phase 1 ----
-                if (DEAL && kt == draw_kt && b == 1) read_tile();
                 read_w(buf + 2 * PP_H_BYTES, whi);
                 stage_slot(S0{});
                 stage_slot(S1{});
@@ -723,7 +666,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
             mfma_quad(acc[0], 0, wlo);
             __builtin_amdgcn_s_barrier();
             // ---- phase 1 ----
-            if (DEAL && kt == draw_kt && b == 1) read_tile();
             read_w(buf + 2 * PP_H_BYTES, whi);
             stage_slot(S0{});
             __builtin_amdgcn_s_barrier();
@@ -801,20 +743,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             kt = 0;
-            tile = nxt;
-            if (tile < 0) break;
-            if (!DEAL) nxt = tile + G < ntiles ? tile + G : -1;
+            tile += G;
         }
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();  // pairs with the extra barrier of the second group
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead loads past the end of the stream
-    if (DEAL && tid == 0) {  // the last workgroup of the launch to get here leaves the queue entry clean
-        if (atomicAdd(&g_pp_done[queue], 1u) == (unsigned)G - 1u) {
-#pragma unroll
-            for (int x = 0; x < 8; ++x) g_pp_ctr[queue * 8 + x] = 0u;
-            g_pp_done[queue] = 0u;
-        }
-    }
 }
 
 template <int EPI>
@@ -882,8 +815,6 @@ static int launch_nt_persist(const GemmNT& p, hipStream_t s) {
     return MMAE_OK;
 }
 
-static std::atomic<unsigned> g_pp_launches{0};
-
 template <int EPI>
 static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
     static bool reserved = false;
@@ -906,8 +837,7 @@ static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
         if (pl.halves) q.M = pl.full_panels * 256;
         int grid = pl.full_panels * pl.tiles_n;
         if (grid > num_cus()) grid = num_cus();
-        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, false>), dim3(grid), dim3(512), PP_LDS, s, q, pl.full_panels, pl.tiles_n,
-                           (int)(g_pp_launches.fetch_add(1u) % PP_QUEUES));
+        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, false>), dim3(grid), dim3(512), PP_LDS, s, q, pl.full_panels, pl.tiles_n);
         MMAE_CHECK_LAUNCH("gemm_nt_pp");
     }
     if (pl.halves && g_nt_phase != 1) {
@@ -923,8 +853,7 @@ static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
         if (p.aux) q.aux = (const char*)p.aux + r0 * p.ldaux * aux_sz;
         int grid = pl.halves;
         if (grid > num_cus()) grid = num_cus();
-        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true>), dim3(grid), dim3(512), PP_LDS, s, q, (q.M + 127) / 128, pl.tiles_n,
-                           (int)(g_pp_launches.fetch_add(1u) % PP_QUEUES));
+        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true>), dim3(grid), dim3(512), PP_LDS, s, q, (q.M + 127) / 128, pl.tiles_n);
         MMAE_CHECK_LAUNCH("gemm_nt_pp(half tiles)");
     }
     return MMAE_OK;
@@ -951,8 +880,8 @@ static int launch_nt(const GemmNT& p, hipStream_t s) {
     // 128x128 kernels the persistent ring wins for many tiles of a short K loop (N >= 2048), the plain grid elsewhere.
     const long tiles128 = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     g_nt_full_rows = p.M;
-    if (g_nt_variant == 5 && p.K % 128 == 0 && p.K >= 256) { g_last_nt = 5; return launch_nt_pp<EPI>(p, s); }
-    if (g_nt_variant == 0 && p.K % 128 == 0 && p.K >= 256 && EPI != EPI_TOKENS && EPI != EPI_UNPATCH) {
+    if (g_nt_variant == 5 && p.K % 128 == 0) { g_last_nt = 5; return launch_nt_pp<EPI>(p, s); }
+    if (g_nt_variant == 0 && p.K % 128 == 0 && EPI != EPI_TOKENS && EPI != EPI_UNPATCH) {
         const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         const double fill = (double)tiles256 / (pp_plan(p.M, p.N, p.K).rounds * num_cus());
         static double env_fill = -1.0;
