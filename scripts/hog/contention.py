@@ -1,4 +1,5 @@
-"""GEMM time with some CUs held by a long-running kernel of another stream (scripts/hog/hog.hip).
+"""GEMM time with some CUs held by a long-running kernel of another stream (scripts/hog/hog.hip; build it in place with
+`hipcc --offload-arch=gfx950 -O3 -fPIC -shared scripts/hog/hog.hip -o scripts/hog/libhog.so`).
   python scripts/hog/contention.py [path of libmmae_hip.so to load]
 Ten back-to-back launches of a GEMM on the main stream, timed by events, while `H` hog workgroups sit on the chip."""
 import ctypes, os, sys, time
