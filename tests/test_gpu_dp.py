@@ -61,6 +61,16 @@ def _rccl_worker(rank, port, out):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     torch.cuda.synchronize()
     torch.save({"params": step.flat.params.cpu(), "gn2": gn2.cpu(), "loss": loss.cpu(), "t": t.cpu()}, out)
+    # a further step with the model's own mask draws under torch's synchronisation check: the bucketed all-reduces, their
+    # waits and the optimizer's join must not make the host wait for the device
+    step(x)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        step(x)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()
 
