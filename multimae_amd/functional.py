@@ -111,21 +111,28 @@ def join_side_stream(device=None):
 
 
 # The output adapters (decoders) are independent of each other between the encoder output and the losses, and their
-# GEMMs are small (196 tiles of 256x256 on 256 CUs, short K): each runs on a stream of its own so that the workgroups of
-# one fill the CUs another leaves idle.  Autograd runs every backward node on the stream its forward ran on.
+# GEMMs are small (196 tiles of 256x256 on 256 CUs, short K): they are dealt over two streams so that the workgroups of
+# one decoder fill the CUs another leaves idle.  Autograd runs every backward node on the stream its forward ran on.
 DECODER_STREAMS = os.environ.get("MMAE_DEC_STREAMS", "1") != "0"
+_DEC_LAYOUT = os.environ.get("MMAE_DEC_LAYOUT", "")  # "<aux streams>[+main]" overrides the default below (tuning)
 _AUX = {}  # device index -> [streams, used since the last join]
 
 
-def decoder_streams_enabled() -> bool:
-    """Single-rank runs only.  A process gets 4 hardware queues (GPU_MAX_HW_QUEUES); streams beyond that share one, and
-    kernels of streams that share a queue run in submission order.  With the main, weight-gradient and RCCL streams a
-    multi-rank step already uses three; three more would put a compute stream behind the all-reduce kernels, which stay
-    resident until every peer has arrived, and the overlap of communication with backward would be lost."""
-    if not DECODER_STREAMS:
-        return False
-    import torch.distributed as dist
-    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+def decoder_lanes(device, n_decoders: int):
+    """Streams the decoders are dealt over, or None for "all on the current stream": the current stream and one decoder
+    stream, decoders alternating.  A process gets 4 hardware queues (GPU_MAX_HW_QUEUES; more are time-sliced and cost a
+    third of the throughput); streams beyond that share a queue, and kernels of streams that share a queue run in
+    submission order.  With the weight-gradient stream and, in a multi-rank run, the RCCL stream that makes four:
+    no compute stream ever queues behind an all-reduce kernel waiting for its peers.  (One stream per decoder measured
+    the same as this layout, 29.7 ms per step on one box.)"""
+    if not DECODER_STREAMS or n_decoders < 2:
+        return None
+    if _DEC_LAYOUT:
+        n_aux, with_main = int(_DEC_LAYOUT.split("+")[0]), _DEC_LAYOUT.endswith("+main")
+    else:
+        n_aux, with_main = 1, True
+    aux = aux_streams(device, min(n_aux, n_decoders))
+    return ([torch.cuda.current_stream(device)] if with_main else []) + aux
 
 
 def aux_streams(device, n: int):

@@ -217,19 +217,22 @@ class MultiMAE(nn.Module):
         def decode(d):
             return self.output_adapters[d](encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep,
                                            ids_restore=ids_restore, fp32_output=d in fp32_output_adapters)
-        if Fn.decoder_streams_enabled() and encoder_tokens.is_cuda and len(self.output_adapters) > 1:
-            # one stream per decoder (they are independent until the losses); same kernels, same order per decoder, so the
-            # results do not change
+        lanes = Fn.decoder_lanes(encoder_tokens.device, len(self.output_adapters)) if encoder_tokens.is_cuda else None
+        if lanes is not None:
+            # the decoders are independent until the losses: dealt over the main stream and the decoder streams; same
+            # kernels, same order per decoder, so the results do not change
             main = torch.cuda.current_stream(encoder_tokens.device)
-            streams = Fn.aux_streams(encoder_tokens.device, len(self.output_adapters))
-            preds = {}
-            for st, d in zip(streams, self.output_adapters):
-                st.wait_stream(main)
+            preds, where = {}, {}
+            for i, d in enumerate(self.output_adapters):
+                st = where[d] = lanes[i % len(lanes)]
+                if st != main:
+                    st.wait_stream(main)
                 with torch.cuda.stream(st):
                     preds[d] = decode(d)
-            for st, d in zip(streams, self.output_adapters):
-                main.wait_stream(st)
-                preds[d].record_stream(main)
+            for d, st in where.items():
+                if st != main:
+                    main.wait_stream(st)
+                    preds[d].record_stream(main)
             return preds, task_masks
         return {d: decode(d) for d in self.output_adapters}, task_masks
 
