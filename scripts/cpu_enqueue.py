@@ -5,6 +5,11 @@ import torch
 from multimae_amd.builders import build_losses, build_multimae
 from multimae_amd.train import PretrainStep
 
+if os.environ.get("MMAE_DP_SINGLE_RANK") == "1":  # the same through a one-rank RCCL group (bucket hooks, all-reduce calls)
+    from multimae_amd.train import init_distributed_mode
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29537")
+    os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
+    init_distributed_mode()
 torch.manual_seed(0)
 model = build_multimae().cuda()
 step = PretrainStep(model, build_losses(), num_encoded_tokens=98, alphas=1.0, lr=1e-4, weight_decay=0.05)
