@@ -141,7 +141,7 @@ def main():
     if not args.no_roofline:
         # Two more steps with a HIP-event pair around every GEMM / attention launch (on the stream it is launched on).
         # Every rank runs them (the step holds collectives); rank 0 records.  The weight-gradient stream is switched off
-        # here, and so are the per-decoder streams, so that a kernel's duration is its own, not that of kernels sharing the chip.
+        # here, and so is the decoder stream, so that a kernel's duration is its own, not that of kernels sharing the chip.
         from multimae_amd import functional as Fn
         side, dec = Fn.SIDE_STREAM_DW, Fn.DECODER_STREAMS
         Fn.SIDE_STREAM_DW = Fn.DECODER_STREAMS = False

@@ -502,8 +502,8 @@ def test_reference_style_loop_with_utils_helpers():
 
 
 def test_decoder_streams_do_not_change_the_step():
-    """One stream per output adapter (default) against everything on one stream: same kernels in the same order per
-    decoder, so three optimisation steps must end on bitwise identical parameters."""
+    """Decoders dealt over the main stream and a decoder stream (default) against everything on one stream: same kernels
+    in the same order per decoder, so three optimisation steps must end on bitwise identical parameters."""
     from oracle import multimae_oracle as O
     from tests.golden import common as G
     from multimae_amd import functional as Fn
