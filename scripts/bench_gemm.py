@@ -2,6 +2,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from multimae_amd import _lib
+if os.environ.get("BENCH_LIB"):  # another build of the library (A/B on one box)
+    _lib.LIB_PATH = os.path.abspath(os.environ["BENCH_LIB"])
 from multimae_amd import ops
 
 
