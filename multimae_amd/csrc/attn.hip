@@ -120,11 +120,17 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p, int nkp) 
         float m = -INFINITY;
         for (int kt = 0; kt < nkt; ++kt) {
             const f32x16 a = score_tile<D>(Ks, kt, r, h2, qf);
-            const int lim = kt == nkt - 1 ? tail : 32;
+            // only the last key tile has padded keys to mask (workgroup-uniform test; the vector ALU bounds these kernels)
+            if (kt == nkt - 1 && tail < 32) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) m = fmaxf(m, acc_row(i, h2) < lim ? a[i] : -INFINITY);
+                for (int i = 0; i < 16; ++i) m = fmaxf(m, acc_row(i, h2) < tail ? a[i] : -INFINITY);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) m = fmaxf(m, a[i]);
+            }
         }
         m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float mc = -m * c;
 
         float l = 0.f;
         f32x16 oacc[DT];
@@ -132,12 +138,20 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p, int nkp) 
         for (int dt = 0; dt < DT; ++dt) oacc[dt] = zero16();
         for (int kt = 0; kt < nkt; ++kt) {
             f32x16 a = score_tile<D>(Ks, kt, r, h2, qf);
-            const int lim = kt == nkt - 1 ? tail : 32;
+            if (kt == nkt - 1 && tail < 32) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float e = acc_row(i, h2) < lim ? __builtin_amdgcn_exp2f((a[i] - m) * c) : 0.f;
-                a[i] = e;
-                l += e;
+                for (int i = 0; i < 16; ++i) {
+                    const float e = acc_row(i, h2) < tail ? __builtin_amdgcn_exp2f(fmaf(a[i], c, mc)) : 0.f;
+                    a[i] = e;
+                    l += e;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(a[i], c, mc));
+                    a[i] = e;
+                    l += e;
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, 
 #pragma unroll
         for (int m = 1; m < CH; m <<= 1) part += __shfl_xor(part, m, 64);
         if (ch == 0) {
-            delta[n] = part;
+            delta[n] = -part * p.scale;  // kept negated and scaled: dS = P * fma(dP, scale, delta), one instruction fewer per score
             lse2[n] = n < p.q_len ? p.lse[((long)b * p.H + h) * p.q_len + n] * LOG2E : 1e30f;  // padded rows: every probability 0
         }
     }
@@ -437,12 +451,20 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, 
                     s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Ks, kt * 32 + r, ks, h2), qf[ks], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vs, kt * 32 + r, ks, h2), dof[ks], dp, 0, 0, 0);
                 }
-                const int lim = kt == nkt - 1 ? tail : 32;
+                // the vector ALU bounds this kernel: only the last key tile has padded keys to mask (workgroup-uniform test)
+                if (kt == nkt - 1 && tail < 32) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float pr = acc_row(i, h2) < lim ? __builtin_amdgcn_exp2f(s[i] * c - my_lse) : 0.f;
-                    s[i] = pr * (dp[i] - my_delta) * p.scale;
-                    rs += (float)(bf16)s[i];
+                    for (int i = 0; i < 16; ++i) {
+                        const float pr = acc_row(i, h2) < tail ? __builtin_amdgcn_exp2f(s[i] * c - my_lse) : 0.f;
+                        s[i] = pr * fmaf(dp[i], p.scale, my_delta);
+                        rs += (float)(bf16)s[i];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        s[i] = __builtin_amdgcn_exp2f(s[i] * c - my_lse) * fmaf(dp[i], p.scale, my_delta);
+                        rs += (float)(bf16)s[i];
+                    }
                 }
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -472,6 +494,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, 
             // ---- dK, dV of a 32-key tile (see attn_bwd_dkv_kernel) ----
             const int key = (item - nqt) * 32 + r;
             const bool key_valid = key < p.kv_len;
+            const bool some_invalid = (item - nqt) == nkt - 1 && tail < 32;
             // the tile's own K / V fragments are re-read from LDS per query block (opaque row index, so that the reads
             // are not hoisted): holding them would take 2 * D / 2 more registers than four waves per SIMD leave
             f32x16 dk[DT], dv[DT];
@@ -493,9 +516,12 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int i = 4 * i4 + e;
-                        const float pr = key_valid ? __builtin_amdgcn_exp2f(s[i] * c - lv[e]) : 0.f;
+                        float pr = __builtin_amdgcn_exp2f(s[i] * c - lv[e]);
+                        // only the last key tile can hold padded keys; at head_dim 64 the wave-uniform test around the
+                        // select measured faster (133 -> 126 us at 99 tokens), at 32 slower (103 -> 106 us at 196)
+                        if (D != 64 || some_invalid) pr = key_valid ? pr : 0.f;
                         s[i] = pr;
-                        dp[i] = pr * (dp[i] - dl[e]) * p.scale;
+                        dp[i] = pr * fmaf(dp[i], p.scale, dl[e]);
                     }
                 }
 #pragma unroll

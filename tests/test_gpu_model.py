@@ -319,8 +319,11 @@ def test_vit_b_rgb_depth_semseg_step_vs_oracle():
 
 
 def test_pretrain_step_applies_schedules_and_clipping():
-    """PretrainStep with per-iteration lr / weight-decay arrays and gradient clipping equals autograd delivery +
-    clip_grad_norm_ + torch AdamW with the same per-step values."""
+    """PretrainStep with per-iteration lr / weight-decay arrays and gradient clipping equals clip_grad_norm_ + torch AdamW
+    with the same per-step values, fed the gradients of the same steps.  (The reference optimizer gets the step's own
+    gradients rather than those of a second model stepping beside it: the key bias has no gradient in exact arithmetic,
+    what arrives is rounding noise that Adam normalises to steps of +-lr, and two models agree on noise only as long as
+    every bit of their weights agrees.  Gradient delivery itself is test_flat_storage_step_matches_autograd_path.)"""
     from oracle import multimae_oracle as O
     from tests.golden import common as G
     from multimae_amd.train import PretrainStep, cosine_scheduler, split_decay
@@ -332,24 +335,25 @@ def test_pretrain_step_applies_schedules_and_clipping():
     wds = cosine_scheduler(0.05, 0.1, 1, 4)
     clip = 0.5
 
-    ref = _build(cfg); ref.load_state_dict(sd); ref.cuda()
-    decay, no_decay = split_decay(ref)
-    opt = torch.optim.AdamW([{"params": [p for _, p in decay], "weight_decay": 0.05},
-                             {"params": [p for _, p in no_decay], "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.95))
     model = _build(cfg); model.load_state_dict(sd); model.cuda()
+    decay, no_decay = split_decay(model)
+    ref = {n: torch.nn.Parameter(p.detach().clone()) for n, p in decay + no_decay}
+    opt = torch.optim.AdamW([{"params": [ref[n] for n, _ in decay], "weight_decay": 0.05},
+                             {"params": [ref[n] for n, _ in no_decay], "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.95))
     step = PretrainStep(model, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05, clip_grad=clip,
                         lr_schedule_values=lrs, wd_schedule_values=wds)
     for it in range(3):
         opt.param_groups[0]["lr"] = opt.param_groups[1]["lr"] = float(lrs[it])
         opt.param_groups[0]["weight_decay"] = float(wds[it])
-        _hip_step(ref, cfg, {d: t.cpu() for d, t in x.items()}, rnd, 8)
-        total = torch.nn.utils.clip_grad_norm_([p for p in ref.parameters() if p.requires_grad], clip)
-        opt.step()
         loss, _, gn2 = step(x, mask_randomness=rnd)
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                ref[n].grad = p.grad.detach().clone()  # the step's gradients (clipping is a factor inside the optimizer kernel)
+        total = torch.nn.utils.clip_grad_norm_(list(ref.values()), clip)
+        opt.step()
         assert abs(gn2.sqrt().item() - total.item()) / total.item() < 1e-4 and total.item() > clip  # clipping is active
-    named = dict(ref.named_parameters())
-    worst = max(rel_err(p.detach(), named[n].detach()) for n, p in model.named_parameters() if p.requires_grad)
-    assert worst < 2e-5, worst
+        worst = max(rel_err(p.detach(), ref[n].detach()) for n, p in model.named_parameters() if p.requires_grad)
+        assert worst < 2e-6, (it, worst)
 
 
 def test_standalone_mlp_attention_cross_attention_vs_oracle():
