@@ -122,8 +122,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p, int nkp) 
             const f32x16 a = score_tile<D>(Ks, kt, r, h2, qf);
             // only the last key tile has padded keys to mask (workgroup-uniform test; the vector ALU bounds these kernels)
             if (kt == nkt - 1 && tail < 32) {
+                // accumulator registers 4g..4g+3 hold key rows 8g..8g+7 of the tile: groups past the last key are skipped
 #pragma unroll
-                for (int i = 0; i < 16; ++i) m = fmaxf(m, acc_row(i, h2) < tail ? a[i] : -INFINITY);
+                for (int g = 0; g < 4; ++g)
+                    if (8 * g < tail) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) m = fmaxf(m, acc_row(4 * g + e, h2) < tail ? a[4 * g + e] : -INFINITY);
+                    }
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) m = fmaxf(m, a[i]);
@@ -138,12 +143,22 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p, int nkp) 
         for (int dt = 0; dt < DT; ++dt) oacc[dt] = zero16();
         for (int kt = 0; kt < nkt; ++kt) {
             f32x16 a = score_tile<D>(Ks, kt, r, h2, qf);
+            const bool short_tail = kt == nkt - 1 && tail <= 16;  // the second k-step of P V would multiply zeros
             if (kt == nkt - 1 && tail < 32) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float e = acc_row(i, h2) < tail ? __builtin_amdgcn_exp2f(fmaf(a[i], c, mc)) : 0.f;
-                    a[i] = e;
-                    l += e;
+                for (int g = 0; g < 4; ++g) {
+                    if (8 * g < tail) {
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) {
+                            const int i = 4 * g + e4;
+                            const float e = acc_row(i, h2) < tail ? __builtin_amdgcn_exp2f(fmaf(a[i], c, mc)) : 0.f;
+                            a[i] = e;
+                            l += e;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) a[4 * g + e4] = 0.f;
+                    }
                 }
             } else {
 #pragma unroll
@@ -155,6 +170,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p, int nkp) 
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
+                if (s2 == 1 && short_tail) continue;
                 const bf16x8 pf = pack8(a, s2);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
@@ -452,12 +468,24 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, 
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vs, kt * 32 + r, ks, h2), dof[ks], dp, 0, 0, 0);
                 }
                 // the vector ALU bounds this kernel: only the last key tile has padded keys to mask (workgroup-uniform test)
+                // (skipping padded groups and k-steps pays at head_dim 64 only: 124 -> 122 us there, 66 -> 70 us at 32 with 99 keys)
+                const bool short_tail = D == 64 && kt == nkt - 1 && tail <= 16;  // the second k-step of dQ would multiply zeros
                 if (kt == nkt - 1 && tail < 32) {
+                    // accumulator registers 4g..4g+3 hold key rows 8g..8g+7 of the tile: groups past the last key are skipped
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float pr = acc_row(i, h2) < tail ? __builtin_amdgcn_exp2f(s[i] * c - my_lse) : 0.f;
-                        s[i] = pr * fmaf(dp[i], p.scale, my_delta);
-                        rs += (float)(bf16)s[i];
+                    for (int g = 0; g < 4; ++g) {
+                        if (D != 64 || 8 * g < tail) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int i = 4 * g + e;
+                                const float pr = acc_row(i, h2) < tail ? __builtin_amdgcn_exp2f(s[i] * c - my_lse) : 0.f;
+                                s[i] = pr * fmaf(dp[i], p.scale, my_delta);
+                                rs += (float)(bf16)s[i];
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) s[4 * g + e] = 0.f;
+                        }
                     }
                 } else {
 #pragma unroll
@@ -468,6 +496,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, 
                 }
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
+                    if (s2 == 1 && short_tail) continue;
                     const bf16x8 dsf = pack8(s, s2);
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt)
@@ -509,8 +538,14 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, 
                     s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Qs, qb * 32 + r, ks, h2), row_frag<D>(Ks, krow, ks, h2), s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(dOs, qb * 32 + r, ks, h2), row_frag<D>(Vs, krow, ks, h2), dp, 0, 0, 0);
                 }
+                const int qleft = p.q_len - qb * 32;  // queries of this block; registers 4g..4g+3 hold query rows 8g..8g+7
 #pragma unroll
                 for (int i4 = 0; i4 < 4; ++i4) {
+                    if (D == 64 && 8 * i4 >= qleft) {  // padded queries only (wave-uniform): their probabilities are zero
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s[4 * i4 + e] = dp[4 * i4 + e] = 0.f;
+                        continue;
+                    }
                     const f32x4 lv = *(const f32x4*)(lse2 + qb * 32 + 8 * i4 + 4 * h2);
                     const f32x4 dl = *(const f32x4*)(delta + qb * 32 + 8 * i4 + 4 * h2);
 #pragma unroll
@@ -526,6 +561,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, 
                 }
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
+                    if (D == 64 && s2 == 1 && qleft <= 16) continue;  // the second k-step would multiply zeros
                     const bf16x8 pf = pack8(s, s2), dsf = pack8(dp, s2);
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt) {
