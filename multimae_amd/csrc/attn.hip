@@ -254,6 +254,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs p, int nk
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
         float rs = 0.f;  // this lane's share of rowsum(bf16(dS)) of query r
+        const float nds = -my_delta * p.scale;  // dS = P * fma(dP, scale, nds)
         for (int kt = 0; kt < nkt; ++kt) {
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
@@ -261,12 +262,20 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs p, int nk
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Ks, kt * 32 + r, ks, h2), qf[ks], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vs, kt * 32 + r, ks, h2), dof[ks], dp, 0, 0, 0);
             }
-            const int lim = kt == nkt - 1 ? tail : 32;
+            // only the last key tile has padded keys to mask (workgroup-uniform test; the vector ALU bounds these kernels)
+            if (kt == nkt - 1 && tail < 32) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float pr = acc_row(i, h2) < lim ? __builtin_amdgcn_exp2f(s[i] * c - my_lse) : 0.f;
-                s[i] = pr * (dp[i] - my_delta) * p.scale;
-                rs += (float)(bf16)s[i];
+                for (int i = 0; i < 16; ++i) {
+                    const float pr = acc_row(i, h2) < tail ? __builtin_amdgcn_exp2f(s[i] * c - my_lse) : 0.f;
+                    s[i] = pr * fmaf(dp[i], p.scale, nds);
+                    rs += (float)(bf16)s[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    s[i] = __builtin_amdgcn_exp2f(s[i] * c - my_lse) * fmaf(dp[i], p.scale, nds);
+                    rs += (float)(bf16)s[i];
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
