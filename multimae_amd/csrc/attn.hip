@@ -38,6 +38,18 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& t, int s) {
     return r;
 }
 
+// acc + sum of the eight bf16 values of a packed fragment: four v_dot2c_f32_bf16 against (1, 1) instead of eight
+// widen-and-add pairs (the row sum of dS has to be taken over the rounded values the MFMA sees)
+__device__ __forceinline__ float add_bf16x8(float acc, const bf16x8& v) {
+    typedef __attribute__((ext_vector_type(2))) bf16 bf16x2;
+    const bf16x2 ones = {(bf16)1.0f, (bf16)1.0f};
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 0, 1), ones, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 2, 3), ones, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 4, 5), ones, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 6, 7), ones, acc, false);
+    return acc;
+}
+
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 a;
 #pragma unroll
@@ -210,6 +222,7 @@ template <int D, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs p, int nkp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LDR = D + 8, KS = D / 16, DT = D / 32;
+    constexpr bool RS_DOT2 = D == 32;  // as in attn_bwd_fused_kernel
     bf16* Ks = (bf16*)smem;
     bf16* Vs = Ks + nkp * LDR;
     float* kbar = (float*)(Vs + nkp * LDR);  // [D] mean key
@@ -268,18 +281,19 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs p, int nk
                 for (int i = 0; i < 16; ++i) {
                     const float pr = acc_row(i, h2) < tail ? __builtin_amdgcn_exp2f(s[i] * c - my_lse) : 0.f;
                     s[i] = pr * fmaf(dp[i], p.scale, nds);
-                    rs += (float)(bf16)s[i];
+                    if (!RS_DOT2) rs += (float)(bf16)s[i];
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     s[i] = __builtin_amdgcn_exp2f(s[i] * c - my_lse) * fmaf(dp[i], p.scale, nds);
-                    rs += (float)(bf16)s[i];
+                    if (!RS_DOT2) rs += (float)(bf16)s[i];
                 }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 dsf = pack8(s, s2);
+                if (RS_DOT2) rs = add_bf16x8(rs, dsf);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
                     dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ks, LDR, kt * 32 + 16 * s2, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
@@ -402,6 +416,9 @@ template <int D, int NW>
 __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, int nqp, int nkp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LDR = D + 8, KS = D / 16, DT = D / 32, CH = D / 8;
+    // row sum of bf16(dS): at head_dim 32 from the packed fragments with dot2 instructions (dec self 104 -> 98 us); at 64 the
+    // per-score widen-and-add stays (the dot2 form spills there: 124 -> 126 us)
+    constexpr bool RS_DOT2 = D == 32;
     bf16* Qs = (bf16*)smem;                    // [nqp][LDR]
     bf16* dOs = Qs + nqp * LDR;                // [nqp][LDR]
     bf16* Ks = dOs + nqp * LDR;                // [nkp][LDR]
@@ -489,7 +506,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, 
                                 const int i = 4 * g + e;
                                 const float pr = acc_row(i, h2) < tail ? __builtin_amdgcn_exp2f(s[i] * c - my_lse) : 0.f;
                                 s[i] = pr * fmaf(dp[i], p.scale, my_delta);
-                                rs += (float)(bf16)s[i];
+                                if (!RS_DOT2) rs += (float)(bf16)s[i];
                             }
                         } else {
 #pragma unroll
@@ -500,13 +517,14 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, 
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         s[i] = __builtin_amdgcn_exp2f(s[i] * c - my_lse) * fmaf(dp[i], p.scale, my_delta);
-                        rs += (float)(bf16)s[i];
+                        if (!RS_DOT2) rs += (float)(bf16)s[i];
                     }
                 }
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     if (s2 == 1 && short_tail) continue;
                     const bf16x8 dsf = pack8(s, s2);
+                    if (RS_DOT2) rs = add_bf16x8(rs, dsf);
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt)
                         dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ks, LDR, kt * 32 + 16 * s2, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
