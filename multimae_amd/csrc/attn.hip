@@ -372,7 +372,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs p, int n
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * i4 + e;
-                    const float pr = key_valid ? __builtin_amdgcn_exp2f(s[i] * c - lv[e]) : 0.f;
+                    const float pr = __builtin_amdgcn_exp2f(s[i] * c - lv[e]);  // padded keys: columns that are never stored
                     s[i] = pr;
                     dp[i] = pr * (dp[i] - dl[e]) * p.scale;
                 }
@@ -550,7 +550,6 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, 
             // ---- dK, dV of a 32-key tile (see attn_bwd_dkv_kernel) ----
             const int key = (item - nqt) * 32 + r;
             const bool key_valid = key < p.kv_len;
-            const bool some_invalid = (item - nqt) == nkt - 1 && tail < 32;
             // the tile's own K / V fragments are re-read from LDS per query block (opaque row index, so that the reads
             // are not hoisted): holding them would take 2 * D / 2 more registers than four waves per SIMD leave
             f32x16 dk[DT], dv[DT];
@@ -578,10 +577,9 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int i = 4 * i4 + e;
-                        float pr = __builtin_amdgcn_exp2f(s[i] * c - lv[e]);
-                        // only the last key tile can hold padded keys; at head_dim 64 the wave-uniform test around the
-                        // select measured faster (133 -> 126 us at 99 tokens), at 32 slower (103 -> 106 us at 196)
-                        if (D != 64 || some_invalid) pr = key_valid ? pr : 0.f;
+                        // no mask for padded keys: a key is a column of these tiles (one lane), its probabilities feed only
+                        // its own dK / dV rows, and those are not stored (K and V rows past the end are zero: finite values)
+                        const float pr = __builtin_amdgcn_exp2f(s[i] * c - lv[e]);
                         s[i] = pr;
                         dp[i] = pr * fmaf(dp[i], p.scale, dl[e]);
                     }
