@@ -115,7 +115,7 @@ def join_side_stream(device=None):
 # one decoder fill the CUs another leaves idle.  Autograd runs every backward node on the stream its forward ran on.
 DECODER_STREAMS = os.environ.get("MMAE_DEC_STREAMS", "1") != "0"
 _DEC_LAYOUT = os.environ.get("MMAE_DEC_LAYOUT", "")  # "<aux streams>[+main]" overrides the default below (tuning)
-_AUX = {}  # device index -> [streams, used since the last join]
+_AUX = {}  # device index -> [decoder streams, used since the last join, the stream that shares the decoders with them]
 
 
 def decoder_lanes(device, n_decoders: int):
@@ -132,7 +132,11 @@ def decoder_lanes(device, n_decoders: int):
     else:
         n_aux, with_main = 1, True
     aux = aux_streams(device, min(n_aux, n_decoders))
-    return ([torch.cuda.current_stream(device)] if with_main else []) + aux
+    if not with_main:
+        return aux
+    main = torch.cuda.current_stream(device)
+    _AUX[main.device.index][2] = main  # a join issued from a decoder stream has to wait for this one as well
+    return [main] + aux
 
 
 def aux_streams(device, n: int):
@@ -141,7 +145,7 @@ def aux_streams(device, n: int):
         idx = torch.cuda.current_device()
     ent = _AUX.get(idx)
     if ent is None:
-        ent = _AUX[idx] = [[], False]
+        ent = _AUX[idx] = [[], False, None]
     while len(ent[0]) < n:
         ent[0].append(torch.cuda.Stream(device=idx))
     ent[1] = True
@@ -149,11 +153,13 @@ def aux_streams(device, n: int):
 
 
 def join_aux_streams(device=None, reset: bool = True):
-    """Make the current stream wait for the decoder streams (before anything reads what their kernels wrote in place)."""
+    """Make the current stream wait for every stream the decoders ran on (before anything reads what their kernels wrote
+    in place).  The current stream may itself be a decoder stream: a gradient bucket can complete inside a decoder's
+    backward, while kernels of another decoder that write the same bucket are still queued on the main stream."""
     for idx, ent in _AUX.items():
         if ent[1] and (device is None or torch.device(device).index in (None, idx)):
             cur = torch.cuda.current_stream(idx)
-            for st in ent[0]:
+            for st in ent[0] + ([ent[2]] if ent[2] is not None else []):
                 if st != cur:
                     cur.wait_stream(st)
             if reset:
