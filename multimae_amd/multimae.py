@@ -223,10 +223,11 @@ class MultiMAE(nn.Module):
             # kernels, same order per decoder, so the results do not change
             main = torch.cuda.current_stream(encoder_tokens.device)
             preds, where = {}, {}
-            for i, d in enumerate(self.output_adapters):
-                st = where[d] = lanes[i % len(lanes)]
+            for st in lanes:  # before any decoder is queued: a later wait would put that lane behind the decoders on main
                 if st != main:
                     st.wait_stream(main)
+            for i, d in enumerate(self.output_adapters):
+                st = where[d] = lanes[i % len(lanes)]
                 with torch.cuda.stream(st):
                     preds[d] = decode(d)
             for d, st in where.items():
