@@ -326,7 +326,7 @@ class PretrainStep:
         self.uniform, self.fp32_out = sample_tasks_uniformly, list(fp32_output_adapters)
         self.standardize_depth = standardize_depth  # truncated standardisation of batch["depth"] (reference :448-459)
         self.flat = FlatParams(model)
-        self.buckets = GradBuckets(self.flat, bucket_mb=bucket_mb)
+        self.buckets = GradBuckets(self.flat, bucket_mb=float(os.environ.get("MMAE_BUCKET_MB", bucket_mb)))  # env: tuning
         self.opt = FlatAdamW(self.flat, lr=lr, betas=betas, weight_decay=weight_decay)
         self.world = self.buckets.world
 
