@@ -246,6 +246,9 @@ int mmae_transpose_multi(const void* src_bf16, void* dst_bf16, const int* table,
                          mmae_stream_t stream);
 /* y(bf16) = x(f32) elementwise */
 int mmae_cast_bf16(const float* x, void* y_bf16, long n, mmae_stream_t stream);
+/* One idle workgroup for `us` microseconds on `stream` (no reference counterpart).  The host side times pairs of these on
+ * two streams to learn whether the streams share a hardware queue (a process has 4; streams on one queue do not overlap). */
+int mmae_spin_us(int us, mmae_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -61,6 +61,7 @@ SIGNATURES = {
     "mmae_cast_transpose": (_i, [_p, _i, _i, _p, _p, _p]),
     "mmae_transpose_multi": (_i, [_p, _p, _p, _i, _i, _p]),
     "mmae_cast_bf16": (_i, [_p, _p, _l, _p]),
+    "mmae_spin_us": (_i, [_i, _p]),
 }
 
 

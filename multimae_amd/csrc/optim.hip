@@ -231,3 +231,21 @@ extern "C" int mmae_transpose_multi(const void* src_bf16, void* dst_bf16, const 
     MMAE_CHECK_LAUNCH("transpose_multi");
     return MMAE_OK;
 }
+
+
+// A kernel that occupies one workgroup for `us` microseconds and does nothing else (time-bounded: the wave leaves when the
+// constant-rate clock says so).  The host uses pairs of these to find out whether two streams share a hardware queue:
+// kernels of streams on one queue run one after the other, on different queues side by side.
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int mmae_spin_us(int us, hipStream_t stream) {
+    MMAE_REQUIRE(us > 0 && us <= 100000, MMAE_EINVAL, "spin_us: %d us is outside (0, 100000]", us);
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+        khz = 100000;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, stream, (long long)us * khz / 1000);
+    MMAE_CHECK_LAUNCH("spin_us");
+    return MMAE_OK;
+}

@@ -181,6 +181,7 @@ class MultiMAE(nn.Module):
             elif g != (nh, nw):
                 raise NotImplementedError("all input domains must map to the same token grid")
         device = x[domains[0]].device
+        Fn.prepare_streams(device, len(self.output_adapters) if self.output_adapters else 0)
         specs = OrderedDict((d, torch.empty((B, nh * nw, 0), device=device)) for d in domains)
         input_info = self.generate_input_info(specs, image_size=(H, W))
 
