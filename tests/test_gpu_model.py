@@ -609,3 +609,24 @@ def test_step_with_its_own_mask_draws_never_waits_for_the_device():
     finally:
         torch.cuda.set_sync_debug_mode("default")
     assert torch.isfinite(loss).item()
+
+
+def test_chosen_streams_run_beside_the_current_one():
+    """functional.concurrent_stream hands out a stream on another hardware queue than the current stream's (and than the
+    ones handed out before): two idle 2-ms kernels queued together must take about the time of one."""
+    from multimae_amd import _lib, functional as Fn
+    lib = _lib.load()
+    assert lib.mmae_spin_us(0, None) != 0  # argument check: the duration must be positive
+    dev = torch.device("cuda", torch.cuda.current_device())
+    main = torch.cuda.current_stream(dev)
+    st = Fn.concurrent_stream(dev)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(main)
+    st.wait_stream(main)
+    _lib.check(lib.mmae_spin_us(2000, main.cuda_stream), "spin_us")
+    _lib.check(lib.mmae_spin_us(2000, st.cuda_stream), "spin_us")
+    main.wait_stream(st)
+    e1.record(main)
+    torch.cuda.synchronize()
+    assert e0.elapsed_time(e1) < 3.0, e0.elapsed_time(e1)
