@@ -11,8 +11,25 @@ from collections import OrderedDict
 from typing import Dict, Iterable, List, Optional
 
 import torch
+import torch.distributed as dist
 
 from .train import FlatAdamW, split_decay
+
+
+def _is_main_process() -> bool:
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
+def _save_on_master(obj, path: str):
+    """Rank 0 writes (reference: save_on_master, utils/checkpoint.py:128-131 there) to a temporary file that is renamed
+    into place, so a reader (latest_checkpoint on another rank, a resume after a crash) never sees a partial file;
+    every rank then waits for the write."""
+    if _is_main_process():
+        tmp = path + ".tmp.%d" % os.getpid()
+        torch.save(obj, tmp)
+        os.replace(tmp, path)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
 
 
 def multivit_pretrained_keys(state_dict_keys: Iterable[str]) -> List[str]:
@@ -87,14 +104,16 @@ def save_model(output_dir: str, epoch: int, model: torch.nn.Module, optimizer: O
     so "scaler" holds an empty state unless one is passed in."""
     os.makedirs(output_dir, exist_ok=True)
     path = os.path.join(output_dir, "checkpoint-%s.pth" % str(epoch))
-    to_save = {"model": OrderedDict((k, v.detach().cpu().clone()) for k, v in model.state_dict().items()), "epoch": epoch,
-               "scaler": dict(scaler_state or {}), "args": args}
-    if optimizer is not None:
-        osd = optimizer_state_dict(optimizer, model)
-        for st in osd["state"].values():
-            st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].cpu(), st["exp_avg_sq"].cpu()
-        to_save["optimizer"] = osd
-    torch.save(to_save, path)
+    to_save = None
+    if _is_main_process():  # the replicas are identical: only the writer gathers 94 M parameters and their moments
+        to_save = {"model": OrderedDict((k, v.detach().cpu().clone()) for k, v in model.state_dict().items()), "epoch": epoch,
+                   "scaler": dict(scaler_state or {}), "args": args}
+        if optimizer is not None:
+            osd = optimizer_state_dict(optimizer, model)
+            for st in osd["state"].values():
+                st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].cpu(), st["exp_avg_sq"].cpu()
+            to_save["optimizer"] = osd
+    _save_on_master(to_save, path)
     return path
 
 
@@ -102,9 +121,11 @@ def save_model_for_downstream_tasks(output_dir: str, run_name: str, epoch: int, 
     """Encoder-side export multimae_<run>_e<epoch>.pth (utils/checkpoint.py:143-159)."""
     os.makedirs(output_dir, exist_ok=True)
     path = os.path.join(output_dir, f"multimae_{run_name}_e{epoch}.pth")
-    sd = model.state_dict()
-    selected = OrderedDict((k, sd[k].detach().cpu().clone()) for k in multivit_pretrained_keys(sd.keys()))
-    torch.save(OrderedDict(model=selected), path)
+    selected = None
+    if _is_main_process():
+        sd = model.state_dict()
+        selected = OrderedDict((k, sd[k].detach().cpu().clone()) for k in multivit_pretrained_keys(sd.keys()))
+    _save_on_master(OrderedDict(model=selected), path)
     return path
 
 

@@ -3,6 +3,8 @@
     import multimae_amd.compat; multimae_amd.compat.install()
     from multimae import MultiMAE                      # -> multimae_amd.MultiMAE
     from multimae.criterion import MaskedMSELoss       # -> multimae_amd.criterion.MaskedMSELoss
+    import utils; from utils import create_model       # -> multimae_amd.utils (the step-side helpers of the reference's utils)
+    from utils.optim_factory import create_optimizer   # -> multimae_amd.optim_factory.create_optimizer
 """
 import sys
 
@@ -13,6 +15,8 @@ _ALIASES = {
     "multimae.input_adapters": "multimae_amd.input_adapters",
     "multimae.output_adapters": "multimae_amd.output_adapters",
     "multimae.criterion": "multimae_amd.criterion",
+    "utils": "multimae_amd.utils",
+    "utils.optim_factory": "multimae_amd.optim_factory",
 }
 
 

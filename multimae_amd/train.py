@@ -67,6 +67,8 @@ class FlatParams:
             return sorted(named[::-1], key=lambda np_: rank(np_[0]))
         decay, no_decay = backward_order(decay), backward_order(no_decay)
         self.named = decay + no_decay
+        # frozen parameters and buffers: not in flat storage, but part of what a data-parallel start-up broadcasts
+        self.frozen = [p for _, p in model.named_parameters() if not p.requires_grad] + [b for _, b in model.named_buffers()]
         dev = self.named[0][1].device
 
         def padded(n):  # keep every view 16-byte aligned, in the fp32 buffers and in their bf16 copies
@@ -132,11 +134,21 @@ class FlatParams:
 
 
 class GradBuckets:
-    """Bucketed SUM all-reduce of FlatParams.grads, launched from post-accumulate-grad hooks as buckets complete."""
+    """Bucketed SUM all-reduce of FlatParams.grads, launched from post-accumulate-grad hooks as buckets complete.
 
-    def __init__(self, flat: FlatParams, bucket_mb: float = 64.0, group=None):
+    Construction broadcasts rank 0's parameters (flat storage, frozen parameters, buffers) to the group, the way the
+    reference's DistributedDataParallel wrap does (run_pretraining_multimae.py:224-226; the script seeds each rank with
+    seed + rank before it builds the model, :147-148, so the ranks' own initialisations differ).
+
+    `no_sync` = True suspends the exchange for gradient accumulation: hooks return at once and gradients keep
+    accumulating locally; the first backward after it is cleared all-reduces the accumulated sums."""
+
+    def __init__(self, flat: FlatParams, bucket_mb: float = 64.0, group=None, broadcast: bool = True):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.no_sync = False
+        if broadcast and self.world > 1:
+            self.broadcast_parameters()
         cap = int(bucket_mb * (1 << 20) / 4)
         # The all-reduce of the bucket that completes last cannot hide under backward, so the buckets taper towards the
         # end of the (large) decayed region: the last one holds about cap / 4, the one before it cap / 2.
@@ -172,8 +184,19 @@ class GradBuckets:
                 p.register_post_accumulate_grad_hook(hook)      # gradients delivered by autograd
                 p._mmae_ready = (lambda h=hook, q=p: h(q))       # gradients the kernels wrote in place
 
+    def broadcast_parameters(self, src: int = 0):
+        """Every rank takes rank `src`'s parameters and buffers; the bf16 weight copies are rebuilt from them."""
+        src_global = dist.get_global_rank(self.group, src) if self.group is not None else src
+        with torch.no_grad():
+            dist.broadcast(self.flat.params, src=src_global, group=self.group)
+            for t in self.flat.frozen:
+                dist.broadcast(t.data, src=src_global, group=self.group)
+        self.flat.sync_bf16()
+
     def _make_hook(self, i):
         def hook(_p):
+            if self.no_sync:
+                return
             # A parameter signals once per step.  Autograd also runs the post-accumulate hook of a parameter whose
             # gradient a kernel wrote in place (the Function returned None for it), after the kernel's own signal.
             if self.signalled[i]:
@@ -209,7 +232,7 @@ class GradBuckets:
 
     def finish(self):
         """Call after backward: launches any bucket whose parameters received no gradient, waits for all."""
-        if not self.enabled:
+        if not self.enabled or self.no_sync:
             return
         for b, left in enumerate(self.pending):
             if left > 0:
@@ -261,18 +284,25 @@ class FlatAdamW:
     def step(self, grad_scale: float = 1.0, clip_grad: Optional[float] = None, skip_grad: Optional[float] = None,
              grad_sumsq: Optional[torch.Tensor] = None):
         """grad_sumsq: device scalar sum(g^2) of the raw gradient buffer (computed here if clipping / skipping needs it).
-        With skip_grad the number of applied updates lives on the device (no host synchronisation)."""
+        With skip_grad the number of applied updates lives on the device (no host synchronisation).
+        As in the reference's scaler (utils/native_scaler.py:35-46) clipping takes precedence: with clip_grad given
+        (None = off; any number, 0.0 included, clips) skip_grad is ignored."""
         if self.param_groups[1]["lr"] != self.param_groups[0]["lr"]:
             raise ValueError("FlatAdamW applies one learning rate to both parameter groups")
         Fn.join_side_stream(self.flat.grads.device)
         self.step_count += 1
-        if (clip_grad or skip_grad) and grad_sumsq is None:
+        if clip_grad is not None:
+            skip_grad = None
+            clip_grad = max(float(clip_grad), 1e-30)  # the kernel reads 0 as "no clipping"; a zero bound scales to nothing
+        elif skip_grad is not None and not skip_grad > 0:
+            skip_grad = 1e-30                         # norm >= 0 always holds: every step is skipped, as in the reference
+        if (clip_grad is not None or skip_grad is not None) and grad_sumsq is None:
             grad_sumsq = self.grad_norm_sq()
-        if skip_grad and self.step_dev is None:
+        if skip_grad is not None and self.step_dev is None:
             self.step_dev = torch.full((1,), self.step_count - 1, dtype=torch.int32, device=self.flat.params.device)
         ops.adamw_flat(self.flat.params, self.flat.grads, self.exp_avg, self.exp_avg_sq, self.flat.n_decay, self.lr,
                        self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale,
-                       w_bf16=self.flat.w_bf16, grad_sumsq=grad_sumsq if (clip_grad or skip_grad) else None,
+                       w_bf16=self.flat.w_bf16, grad_sumsq=grad_sumsq if (clip_grad is not None or skip_grad is not None) else None,
                        max_norm=clip_grad or 0.0, skip_norm=skip_grad or 0.0, step_dev=self.step_dev)
         self.flat.refresh_transposes()
         Fn.bump_weight_epoch()

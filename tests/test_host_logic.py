@@ -85,6 +85,21 @@ def test_compat_aliases():
         from multimae.criterion import MaskedL1Loss, MaskedMSELoss  # noqa: F401
         from multimae.multimae import pretrain_multimae_base  # noqa: F401
         assert MultiMAE is multimae_amd.MultiMAE and MaskedMSELoss is multimae_amd.MaskedMSELoss
+        # the names the reference's training script imports for the step (run_pretraining_multimae.py:38-53 there), minus
+        # data loading, logging and argument parsing
+        import utils
+        from multimae.criterion import MaskedCrossEntropyLoss  # noqa: F401
+        from multimae.input_adapters import PatchedInputAdapter as PIA, SemSegInputAdapter  # noqa: F401
+        from multimae.output_adapters import SpatialOutputAdapter as SOA  # noqa: F401
+        from utils import NativeScalerWithGradNormCount as NativeScaler
+        from utils import create_model
+        from utils.optim_factory import create_optimizer
+        import multimae_amd.utils as U
+        assert utils is U and create_optimizer is U.create_optimizer and create_model is multimae_amd.create_model
+        assert NativeScaler is U.NativeScalerWithGradNormCount
+        for name in ("get_world_size", "get_rank", "is_main_process", "cosine_scheduler", "auto_load_model", "save_model",
+                     "init_distributed_mode"):
+            assert callable(getattr(utils, name)), name
     finally:
         compat.uninstall(prev)
     assert sys.modules.get("multimae") is not multimae_amd
@@ -168,6 +183,86 @@ def test_grad_buckets_world2_gloo(tmp_path):
     data = torch.randn(2, 5, 8, generator=g)
     (m(data[0]).pow(2).sum() + m(data[1]).pow(2).sum()).backward()
     assert torch.allclose(summed, flat.grads, rtol=1e-5, atol=1e-6)
+
+
+def _dp_start_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from multimae_amd import checkpoint as CK
+    from multimae_amd.train import FlatParams, GradBuckets, init_distributed_mode
+    init_distributed_mode("gloo")
+    torch.manual_seed(100 + rank)  # seed + rank before the model is built, as the reference's script does
+    m = _Toy()
+    m.register_buffer("table", torch.randn(3))
+    m.tok.data.normal_()
+    own = torch.cat([p.detach().flatten() for p in m.parameters()]).clone()
+    flat = FlatParams(m)
+    buckets = GradBuckets(flat, bucket_mb=0.0004)  # broadcasts rank 0's parameters and buffers
+    after = torch.cat([p.detach().flatten() for p in m.parameters()] + [m.table]).clone()
+    gathered = [torch.empty_like(after) for _ in range(world)]
+    dist.all_gather(gathered, after)
+    owns = [torch.empty_like(own) for _ in range(world)]
+    dist.all_gather(owns, own)
+    # gradient accumulation: one micro-step with the exchange suspended, then one that all-reduces the accumulated sums
+    g = torch.Generator().manual_seed(10)
+    data = torch.randn(2, world, 5, 8, generator=g)
+    flat.zero_grad()
+    buckets.no_sync = True
+    m(data[0, rank]).pow(2).sum().backward()
+    buckets.finish()
+    local_only = flat.grads.clone()
+    buckets.no_sync = False
+    m(data[1, rank]).pow(2).sum().backward()
+    buckets.finish()
+    path = CK.save_model(os.path.dirname(out), 3, m)  # every rank calls; rank 0 writes
+    if rank == 0:
+        torch.save({"params": gathered, "owns": owns, "grads": flat.grads.clone(), "local_only": local_only, "path": path,
+                    "state": {k: v.clone() for k, v in m.state_dict().items()}}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_start_broadcast_accumulation_and_master_only_save(tmp_path):
+    """Ranks seeded differently hold rank 0's parameters and buffers once the gradient buckets exist; a micro-step under
+    no_sync exchanges nothing and the next one all-reduces the accumulated gradients; save_model writes one file."""
+    out = str(tmp_path / "start.pt")
+    mp.spawn(_dp_start_worker, args=(2, 29400 + os.getpid() % 200, out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert not torch.equal(got["owns"][0], got["owns"][1])       # the ranks' own initialisations differed
+    assert torch.equal(got["params"][0], got["params"][1])       # ... and both now hold rank 0's
+    assert torch.equal(got["params"][0][:got["owns"][0].numel()], got["owns"][0])
+    from multimae_amd.train import FlatParams
+    m = _Toy()
+    m.register_buffer("table", torch.zeros(3))
+    m.load_state_dict(got["state"])
+    flat = FlatParams(m)
+    g = torch.Generator().manual_seed(10)
+    data = torch.randn(2, 2, 5, 8, generator=g)
+    m(data[0, 0]).pow(2).sum().backward()
+    assert torch.allclose(got["local_only"], flat.grads, rtol=1e-5, atol=1e-6)  # nothing was exchanged under no_sync
+    sum(m(data[i, r]).pow(2).sum() for i in range(2) for r in range(2) if (i, r) != (0, 0)).backward()
+    assert torch.allclose(got["grads"], flat.grads, rtol=1e-5, atol=1e-6)
+    files = sorted(os.listdir(tmp_path))
+    assert files == ["checkpoint-3.pth", "start.pt"], files
+    ck = torch.load(got["path"], weights_only=True)
+    assert all(torch.equal(ck["model"][k], v) for k, v in got["state"].items())
+
+
+def test_create_optimizer_takes_the_references_call_shape():
+    """create_optimizer(args, {"model": m}) (run_pretraining_multimae.py:228 of the reference) reads the optimizer fields of
+    the argument object (pretrain_argparser.py:44-64 there) and returns one optimizer carrying its gradient buckets."""
+    from types import SimpleNamespace
+    from multimae_amd import utils as U
+    args = SimpleNamespace(opt="adamw", opt_eps=1e-7, opt_betas=[0.8, 0.9], weight_decay=0.02, blr=1e-4, lr=3e-4)
+    opt = U.create_optimizer(args, {"model": _Toy()})
+    assert isinstance(opt, U.FlatAdamW) and isinstance(opt.buckets, U.GradBuckets)
+    assert (opt.lr, opt.weight_decay, opt.betas, opt.eps) == (3e-4, 0.02, (0.8, 0.9), 1e-7)
+    assert [g["weight_decay"] for g in opt.param_groups] == [0.02, 0.0]
+    args.lr = None
+    assert U.create_optimizer(args, {"model": _Toy()}).lr == 1e-4       # falls back to blr
+    opt2, buckets = U.create_optimizer(_Toy(), lr=1e-3)
+    assert opt2.buckets is buckets and opt2.lr == 1e-3
+    with pytest.raises(NotImplementedError):
+        U.create_optimizer(SimpleNamespace(opt="sgd"), {"model": _Toy()})
 
 
 def test_downstream_export_keys_match_reference_list():
