@@ -1,12 +1,14 @@
-"""Benchmark of the MultiMAE ViT-B/16 RGB-D pretraining step (forward, three masked losses, backward with bucketed
-gradient all-reduce, AdamW) on synthetic 224^2 tensors resident in HBM.
+"""Benchmark of the MultiMAE pretraining step (forward, masked losses, backward with bucketed gradient all-reduce, AdamW)
+on synthetic tensors resident in HBM.  Default workload: ViT-B/16 RGB-D 224^2, 98 visible tokens, 3 decoders, 256 images
+per GPU (the configuration the headline metric is quoted on); --config selects the other pretraining configurations.
 
-  python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus 1 --steps 20 --warmup 5 [--config vitb_rgbd | vitb_rgbd_semseg | vitl384]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  `value` = global images / second (max step time over ranks).  `roofline` is for the GEMM
-kernel family that takes the most time in the step, measured with HIP events around each of its launches in extra,
-untimed steps.  `cpu_baseline` (N=1 only) times the CPU restatement of the same step (oracle/, fp32, batch 4)."""
+kernel that takes the most time in the step, measured with HIP events around each of its launches in extra, untimed
+steps; `roofline.hbm_kernels` gives the same for the bandwidth-bound kernels (masking, losses, LayerNorm, AdamW) against
+the HBM peak.  `cpu_baseline` (N=1 only) times the CPU restatement of the same step (oracle/, fp32, small batch)."""
 import argparse
 import json
 import os
@@ -17,9 +19,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-STEP_GFLOP_PER_IMG = 62.33      # ViT-B RGB-D 224^2, 98 visible tokens, 3 decoders: 3 x forward MACs x 2 (GEMM + attention core)
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
+
+# The pretraining configurations.  gflop = algorithmic FLOPs of one step per image: 3 x forward MACs x 2 over the matrix
+# products and the attention cores as the reference computes them (patch projection counted for every token).
+CONFIGS = {
+    # pretrain_argparser.py:13-64 defaults / cfgs/pretrain/multimae-b_98_rgb-depth_400e.yaml of the reference
+    "vitb_rgbd": dict(model="pretrain_multimae_base", in_domains=("rgb", "depth"), out_domains=("rgb", "depth"), image=224,
+                      k=98, batch=256, gflop=62.33, fp32_out=(), cpu_batch=4,
+                      name="MultiMAE ViT-B/16 RGB+depth 224^2, 98 visible tokens, 3 decoders (rgb, depth, norm_rgb)"),
+    # cfgs/pretrain/multimae-b_98_rgb+-depth-semseg_1600e.yaml:13-28, run_pretraining_multimae.py:72-85
+    "vitb_rgbd_semseg": dict(model="pretrain_multimae_base", in_domains=("rgb", "depth", "semseg"),
+                             out_domains=("rgb", "depth", "semseg"), image=224, k=98, batch=256, gflop=67.01,
+                             fp32_out=("semseg",), cpu_batch=4,
+                             name="MultiMAE ViT-B/16 RGB+depth+semseg(133 classes, stride 4) 224^2, 98 of 588 tokens visible, "
+                                  "4 decoders (rgb, depth, semseg in fp32, norm_rgb)"),
+    # multimae/multimae.py:461-478 (ViT-L: 1024 wide, 24 layers, 16 heads) at 384^2; 288 of 1152 tokens visible (the same
+    # quarter as 98 of 392)
+    "vitl384": dict(model="pretrain_multimae_large", in_domains=("rgb", "depth"), out_domains=("rgb", "depth"), image=384,
+                    k=288, batch=64, gflop=586.3, fp32_out=(), cpu_batch=1,
+                    name="MultiMAE ViT-L/16 RGB+depth 384^2, 288 visible tokens, 3 decoders (rgb, depth, norm_rgb)"),
+}
 
 
 def parse():
@@ -27,42 +48,65 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="vitb_rgbd")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline():
-    """The oracle's CPU step (fp32, batch 4 = the reference's CPU-runnable configuration) on this host's cores."""
+def synthetic_batch(conf, B, device, generator=None):
+    """rgb ~ N(0, 1) (normalised pixels), depth ~ U[0, 1), semseg = uniform class ids at a quarter of the resolution."""
+    import torch
+    S = conf["image"]
+    kw = dict(device=device, generator=generator)
+    x = {"rgb": torch.randn(B, 3, S, S, **kw), "depth": torch.rand(B, 1, S, S, **kw)}
+    if "semseg" in conf["in_domains"]:
+        x["semseg"] = torch.randint(0, 133, (B, S // 4, S // 4), **kw)
+    return x
+
+
+def oracle_cfg(conf):
+    from oracle import multimae_oracle as O
+    if "semseg" in conf["in_domains"]:
+        return O.vit_b_rgbd_semseg_cfg(extra_norm_pix=True, image=conf["image"])
+    if conf["model"] == "pretrain_multimae_large":
+        out = {"rgb": (3, "rgb"), "depth": (1, "depth"), "norm_rgb": (3, "rgb")}
+        return O.make_cfg({"rgb": 3, "depth": 1}, out, dim=1024, depth=24, heads=16, image=conf["image"])
+    return O.vit_b_rgbd_cfg(image=conf["image"])
+
+
+def cpu_baseline(conf):
+    """The oracle's CPU step (fp32, a small batch of the same configuration) on this host's cores."""
     import torch
     from oracle import multimae_oracle as O
-    cfg = O.vit_b_rgbd_cfg()
-    trainer = O.CpuTrainer(cfg, seed=0)
+    trainer = O.CpuTrainer(oracle_cfg(conf), seed=0)
     g = torch.Generator().manual_seed(1234)
-    B = 4
-    x = {"rgb": torch.randn(B, 3, 224, 224, generator=g), "depth": torch.rand(B, 1, 224, 224, generator=g)}
-    for _ in range(2):
-        trainer.step(x, 98, g)
+    B, k = conf["cpu_batch"], conf["k"]
+    x = synthetic_batch(conf, B, "cpu", g)
+    warm = 2 if conf["gflop"] < 100 else 1
+    for _ in range(warm):
+        trainer.step(x, k, g)
     times, begin = [], time.perf_counter()
     while len(times) < 5 or (time.perf_counter() - begin < 12.0 and len(times) < 60):  # about 12 s of CPU work
         t0 = time.perf_counter()
-        trainer.step(x, 98, g)
+        trainer.step(x, k, g)
         times.append(time.perf_counter() - t0)
     n = len(times)
     times.sort()
     med = times[n // 2]
     return {"value": round(B / med, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"ViT-B/16 RGB-D 224^2, 98 visible tokens, 3 decoders, fp32, batch 4: median of {n} steps "
-                      "(fwd + 3 losses + bwd + AdamW, about 12 s) after 2 warm-up, oracle/multimae_oracle.py CpuTrainer"}
+            "sample": f"{conf['name']}, fp32, batch {B}: median of {n} steps (fwd + losses + bwd + AdamW, about 12 s) "
+                      f"after {warm} warm-up, oracle/multimae_oracle.py CpuTrainer"}
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, config="vitb_rgbd"):
     """HBM bytes per launch of `kernel` from the committed counter passes of this same command (rocprofv3 cannot run inside
     the process it profiles): profiles/pmc_traffic.json, written by scripts/pmc_table.py from one --pmc FETCH_SIZE and one
     --pmc WRITE_SIZE run, bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 tallies wide reads at half their size).
     Launch-weighted mean over the grids the kernel ran with; (None, None) when the file or the kernel is missing."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    rel = "profiles/pmc_traffic.json" if config == "vitb_rgbd" else f"profiles/pmc_traffic_{config}.json"
+    path = os.path.join(ROOT, rel)
     try:
         with open(path) as f:
             table = json.load(f)
@@ -75,31 +119,39 @@ def pmc_traffic(kernel):
             cnt += v["launches"]
     if cnt == 0:
         return None, None
-    return int(tot / cnt), "profiles/pmc_traffic.json"
+    return int(tot / cnt), rel
 
 
 def main():
     args = parse()
+    conf = CONFIGS[args.config]
     import torch
     import torch.distributed as dist
+    from multimae_amd import functional as Fn
     from multimae_amd import ops
     from multimae_amd.builders import build_losses, build_multimae
     from multimae_amd.train import PretrainStep, init_distributed_mode
 
     # Rehearsal switches (not used by the measured runs): MMAE_BENCH_BACKEND=gloo and MMAE_BENCH_DEVICE=0 let several ranks
     # share one GPU, which RCCL refuses, to exercise the multi-rank control flow on a one-GPU box.
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", int(os.environ.get("MMAE_BENCH_DEVICE", local)))
+    torch.cuda.set_device(dev)
+    # The step's own streams (weight gradients, decoders) are chosen before the process group exists: the choice times
+    # idle kernels on candidate streams, and must not do so beside a resident collective kernel.
+    Fn.prepare_streams(dev, len(conf["out_domains"]) + 1)
     rank, world, local = init_distributed_mode(os.environ.get("MMAE_BENCH_BACKEND", "nccl"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    dev = torch.device("cuda", int(os.environ.get("MMAE_BENCH_DEVICE", local)))
-    torch.cuda.set_device(dev)
 
-    torch.manual_seed(0)  # identical initial weights on every rank (stands for DDP's rank-0 broadcast)
-    model = build_multimae().to(dev)
-    step = PretrainStep(model, build_losses(), num_encoded_tokens=98, alphas=1.0, lr=1e-4, weight_decay=0.05)
-    torch.manual_seed(1234 + rank)  # per-rank data / mask randomness (seed + rank, as the reference)
-    B = args.batch
-    batch = {"rgb": torch.randn(B, 3, 224, 224, device=dev), "depth": torch.rand(B, 1, 224, 224, device=dev)}
+    torch.manual_seed(0 + rank)  # seed + rank before the model is built, as the reference; rank 0's weights are broadcast
+    model = build_multimae(conf["model"], in_domains=conf["in_domains"], out_domains=conf["out_domains"],
+                           image_size=conf["image"]).to(dev)
+    step = PretrainStep(model, build_losses(conf["out_domains"]), num_encoded_tokens=conf["k"], alphas=1.0, lr=1e-4,
+                        weight_decay=0.05, fp32_output_adapters=conf["fp32_out"])
+    torch.manual_seed(1234 + rank)  # per-rank data / mask randomness
+    B = args.batch or conf["batch"]
+    batch = synthetic_batch(conf, B, dev)
 
     verbose = os.environ.get("MMAE_BENCH_VERBOSE") == "1"
     if verbose:  # where every thread stands if the run is still going after a minute
@@ -136,13 +188,14 @@ def main():
         raise SystemExit(f"non-finite loss {final_loss}")
     ms = elapsed / args.steps * 1e3
     ips = world * B * args.steps / elapsed
+    peak_mem = torch.cuda.max_memory_allocated(dev)
 
     roof = None
     if not args.no_roofline:
-        # Two more steps with a HIP-event pair around every GEMM / attention launch (on the stream it is launched on).
-        # Every rank runs them (the step holds collectives); rank 0 records.  The weight-gradient stream is switched off
-        # here, and so is the decoder stream, so that a kernel's duration is its own, not that of kernels sharing the chip.
-        from multimae_amd import functional as Fn
+        # Two more steps with a HIP-event pair around every GEMM / attention / bandwidth-kernel launch (on the stream it is
+        # launched on).  Every rank runs them (the step holds collectives); rank 0 records.  The weight-gradient stream is
+        # switched off here, and so is the decoder stream, so that a kernel's duration is its own, not that of kernels
+        # sharing the chip.
         side, dec = Fn.SIDE_STREAM_DW, Fn.DECODER_STREAMS
         Fn.SIDE_STREAM_DW = Fn.DECODER_STREAMS = False
         if rank == 0:
@@ -152,10 +205,14 @@ def main():
         sync()
         note("per-kernel timing steps done")
         Fn.SIDE_STREAM_DW, Fn.DECODER_STREAMS = side, dec
-    if roof is None and not args.no_roofline and rank == 0:
-        fam, ker = {}, {}
-        for name, flops, e0, e1, label in ops.PROFILE:
+    if not args.no_roofline and rank == 0:
+        fam, ker, hbm = {}, {}, {}
+        for name, flops, e0, e1, label, nbytes in ops.PROFILE:
             dt = e0.elapsed_time(e1) * 1e-3
+            if nbytes is not None:
+                d = hbm.setdefault(label, [0.0, 0.0, 0])
+                d[0] += nbytes; d[1] += dt; d[2] += 1
+                continue
             for table, key in ((fam, name), (ker, label)):
                 d = table.setdefault(key, [0.0, 0.0, 0])
                 d[0] += flops; d[1] += dt; d[2] += 1
@@ -163,7 +220,15 @@ def main():
         # the dominant kernel = the single kernel (name as rocprofv3 prints it) with the most time per step
         name, (fl, sec, n) = max(((k_, v) for k_, v in ker.items() if v[0] > 0), key=lambda kv: kv[1][1])
         ach = fl / sec / 1e12
-        traffic, traffic_src = pmc_traffic(name)
+        traffic, traffic_src = pmc_traffic(name, args.config)
+
+        def hbm_row(label, v):
+            gbps = v[0] / v[1] / 1e9
+            counter, _ = pmc_traffic(label.split(" ")[0], args.config)
+            return {"bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": round(gbps / PEAK_HBM_GBPS, 4), "algorithmic_bytes_per_launch": int(v[0] / v[2]),
+                    "traffic": counter, "launches_per_step": v[2] // 2, "avg_launch_us": round(v[1] / v[2] * 1e6, 1),
+                    "ms_per_step": round(v[1] / 2 * 1e3, 3)}
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": n // 2,
@@ -172,25 +237,29 @@ def main():
                                  "launches_per_step": v[2] // 2, "avg_launch_us": round(v[1] / v[2] * 1e6, 1)}
                             for k_, v in sorted(ker.items(), key=lambda kv: -kv[1][1])[:8]},
                 "families": {k_: {"tflops": round(v[0] / v[1] / 1e12, 1) if v[0] > 0 else None, "ms_per_step": round(v[1] / 2 * 1e3, 3),
-                                  "launches_per_step": v[2] // 2} for k_, v in fam.items()}}
+                                  "launches_per_step": v[2] // 2} for k_, v in fam.items()},
+                # the bandwidth-bound kernels against the HBM peak: algorithmic bytes (what the kernel must read and
+                # write once) / HIP-event time; `traffic` = counter bytes per launch from the committed passes, when present
+                "hbm_kernels": {k_: hbm_row(k_, v) for k_, v in sorted(hbm.items(), key=lambda kv: -kv[1][1])}}
 
     if rank == 0:
         out = {
-            "metric": "pretrain images/sec (node), MultiMAE ViT-B/16 RGB-D 224^2",
+            "metric": "pretrain images/sec (node), " + conf["name"].split(",")[0],
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": "MultiMAE ViT-B/16 RGB+depth 224^2, 98 visible tokens, 3 decoders (rgb, depth, norm_rgb), "
-                                   "bf16 operands / fp32 accumulate, fwd + losses + bwd + grad all-reduce + AdamW",
-                       "per_gpu_batch": B, "global_batch": world * B, "num_encoded_tokens": 98, "parallelism": f"dp{world}"},
-            "step_gflop_per_image": STEP_GFLOP_PER_IMG,
-            "step_mfma_roofline_frac": round(ips * STEP_GFLOP_PER_IMG * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+            "config": {"workload": conf["name"] + ", bf16 operands / fp32 accumulate, fwd + losses + bwd + grad all-reduce + AdamW",
+                       "name": args.config, "per_gpu_batch": B, "global_batch": world * B, "num_encoded_tokens": conf["k"],
+                       "parallelism": f"dp{world}"},
+            "step_gflop_per_image": conf["gflop"],
+            "step_mfma_roofline_frac": round(ips * conf["gflop"] * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
             "final_loss": round(final_loss, 5),
+            "peak_device_memory_gb": round(peak_mem / 1e9, 2),
         }
         if roof is not None:
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(conf)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

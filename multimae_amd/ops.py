@@ -65,10 +65,12 @@ def _nt_label(epi):
 
 
 class _Timed:
-    """HIP-event pair around one launch when PROFILE is a list: (family, flops, start, end, kernel name as rocprof prints it)."""
+    """HIP-event pair around one launch when PROFILE is a list:
+    (family, flops, start, end, kernel name as rocprof prints it, algorithmic HBM bytes or None).
+    Matrix kernels pass their algorithmic FLOPs, bandwidth-bound kernels `nbytes` (and flops 0.0)."""
 
-    def __init__(self, name, flops, label=None):
-        self.name, self.flops, self.label = name, flops, label
+    def __init__(self, name, flops, label=None, nbytes=None):
+        self.name, self.flops, self.label, self.nbytes = name, flops, label, nbytes
 
     def __enter__(self):
         if PROFILE is not None:
@@ -82,7 +84,8 @@ class _Timed:
             self.e1.record()
             flops = self.flops() if callable(self.flops) else self.flops
             if flops is not None:  # None: nothing was launched
-                PROFILE.append((self.name, flops, self.e0, self.e1, self.label() if callable(self.label) else (self.label or self.name)))
+                PROFILE.append((self.name, flops, self.e0, self.e1, self.label() if callable(self.label) else (self.label or self.name),
+                                self.nbytes))
         return False
 
 
@@ -206,8 +209,9 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
     y = torch.empty(x.shape, dtype=BF16, device=x.device)
     mean = torch.empty((rows,), dtype=F32, device=x.device)
     rstd = torch.empty((rows,), dtype=F32, device=x.device)
-    _lib.check(_L().mmae_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), rows, dim, eps,
-                                       _stream()), "layernorm_fwd")
+    with _Timed("layernorm_fwd", 0.0, "layernorm_fwd_kernel", nbytes=rows * (6 * dim + 8) + 8 * dim):  # x in; y, mean, rstd out
+        _lib.check(_L().mmae_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), rows, dim, eps,
+                                           _stream()), "layernorm_fwd")
     return y, mean, rstd
 
 
@@ -224,18 +228,28 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
     dx = torch.empty(x.shape, dtype=F32, device=x.device)
     dxb = torch.empty(x.shape, dtype=BF16, device=x.device) if want_bf16 else None
     nbytes = _L().mmae_layernorm_bwd_workspace_bytes(rows, dim)
+    # dy (bf16), x, mean, rstd (+ the residual gradient) in; dx (+ its bf16 copy) out
+    moved = rows * (dim * (2 + 4 + (4 if dres is not None else 0) + 4 + (2 if want_bf16 else 0)) + 8)
     if defer_params:
         part = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        _lib.check(_L().mmae_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(dxb),
-                                           None, None, 0, rows, dim, _ptr(part), part.numel(), _stream()), "layernorm_bwd")
+        with _Timed("layernorm_bwd", 0.0, "layernorm_bwd_rows_kernel", nbytes=moved):
+            _lib.check(_L().mmae_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(dxb),
+                                               None, None, 0, rows, dim, _ptr(part), part.numel(), _stream()), "layernorm_bwd")
         return dx, dxb, part, None
     acc = int(dgamma is not None)
     if dgamma is None:
         dgamma = torch.empty((dim,), dtype=F32, device=x.device)
         dbeta = torch.empty((dim,), dtype=F32, device=x.device)
     ws = workspace(nbytes, x.device)
-    _lib.check(_L().mmae_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(dxb),
-                                       _ptr(dgamma), _ptr(dbeta), acc, rows, dim, _ptr(ws), ws.numel(), _stream()), "layernorm_bwd")
+    if PROFILE is None:
+        _lib.check(_L().mmae_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(dxb),
+                                           _ptr(dgamma), _ptr(dbeta), acc, rows, dim, _ptr(ws), ws.numel(), _stream()), "layernorm_bwd")
+    else:  # the row kernel timed on its own, then the parameter reduction as the second launch it is
+        with _Timed("layernorm_bwd", 0.0, "layernorm_bwd_rows_kernel", nbytes=moved):
+            _lib.check(_L().mmae_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(dxb),
+                                               None, None, 0, rows, dim, _ptr(ws), ws.numel(), _stream()), "layernorm_bwd")
+        _lib.check(_L().mmae_layernorm_param_reduce(_ptr(ws), ws.numel(), rows, dim, _ptr(dgamma), _ptr(dbeta), acc, _stream()),
+                   "layernorm_param_reduce")
     return dx, dxb, dgamma, dbeta
 
 
@@ -297,9 +311,12 @@ def mask_generate(task_dist: torch.Tensor, noise: torch.Tensor, noise_all: torch
     keep32 = torch.empty((B, num_encoded), dtype=torch.int32, device=dev)
     restore32 = torch.empty((B, total), dtype=torch.int32, device=dev)
     toks = (C.c_int * T)(*[int(n) for n in tokens_per_task])
-    _lib.check(_L().mmae_mask_generate(_ptr(task_dist), _ptr(noise), _ptr(noise_all), toks, T, B, int(num_encoded),
-                                       _ptr(ids_keep), _ptr(ids_restore), _ptr(mask), _ptr(keep32), _ptr(restore32), _stream()),
-               "mask_generate")
+    # two noise rows and the Dirichlet sample in; int64 ids_keep / ids_restore / mask and the int32 copies out
+    moved = B * (4 * (2 * total + T) + 8 * (num_encoded + 2 * total) + 4 * (num_encoded + total))
+    with _Timed("mask_generate", 0.0, "mask_generate_kernel", nbytes=moved):
+        _lib.check(_L().mmae_mask_generate(_ptr(task_dist), _ptr(noise), _ptr(noise_all), toks, T, B, int(num_encoded),
+                                           _ptr(ids_keep), _ptr(ids_restore), _ptr(mask), _ptr(keep32), _ptr(restore32), _stream()),
+                   "mask_generate")
     return mask, ids_keep, ids_restore, keep32, restore32
 
 
@@ -457,8 +474,11 @@ def masked_loss(kind: int, norm_pix: bool, pred: torch.Tensor, target: torch.Ten
     loss = torch.empty((), dtype=F32, device=pred.device)
     d_pred = torch.empty_like(pred) if want_grad else None
     ws = workspace(_L().mmae_masked_loss_workspace_bytes(B, C_, H, W, patch), pred.device)
-    _lib.check(_L().mmae_masked_loss(kind, int(norm_pix), _ptr(pred), int(pred.dtype == BF16), _ptr(target), _ptr(mask), B, C_, H,
-                                     W, patch, _ptr(loss), _ptr(d_pred), _ptr(ws), ws.numel(), _stream()), "masked_loss")
+    # prediction and target in, gradient out (in the prediction's dtype), the patch mask in
+    moved = pred.numel() * (pred.element_size() * (2 if want_grad else 1) + 4) + (mask.numel() * 8 if mask is not None else 0)
+    with _Timed("masked_loss", 0.0, "loss_main_kernel (with loss_count_kernel, loss_final_kernel)", nbytes=moved):
+        _lib.check(_L().mmae_masked_loss(kind, int(norm_pix), _ptr(pred), int(pred.dtype == BF16), _ptr(target), _ptr(mask), B, C_, H,
+                                         W, patch, _ptr(loss), _ptr(d_pred), _ptr(ws), ws.numel(), _stream()), "masked_loss")
     return loss, d_pred
 
 
@@ -478,8 +498,10 @@ def masked_ce(logits: torch.Tensor, target: torch.Tensor, mask: Optional[torch.T
     loss = torch.empty((), dtype=F32, device=logits.device)
     d_logits = torch.empty_like(logits) if want_grad else None
     ws = workspace(_L().mmae_masked_ce_workspace_bytes(B, H, W), logits.device)
-    _lib.check(_L().mmae_masked_ce(_ptr(logits), int(logits.dtype == BF16), _ptr(target), _ptr(mask), B, C_, H, W, patch,
-                                   float(label_smoothing), _ptr(loss), _ptr(d_logits), _ptr(ws), ws.numel(), _stream()), "masked_ce")
+    moved = logits.numel() * logits.element_size() * (2 if want_grad else 1) + target.numel() * 8
+    with _Timed("masked_ce", 0.0, "ce_main_kernel (with its count / final kernels)", nbytes=moved):
+        _lib.check(_L().mmae_masked_ce(_ptr(logits), int(logits.dtype == BF16), _ptr(target), _ptr(mask), B, C_, H, W, patch,
+                                       float(label_smoothing), _ptr(loss), _ptr(d_logits), _ptr(ws), ws.numel(), _stream()), "masked_ce")
     return loss, d_logits
 
 
@@ -504,9 +526,11 @@ def adamw_flat(p, g, m, v, n_decay, lr, beta1, beta2, eps, weight_decay, step, g
         _req(grad_sumsq, F32, "adamw grad_sumsq")
     if step_dev is not None:
         _req(step_dev, torch.int32, "adamw step_dev")
-    _lib.check(_L().mmae_adamw_flat(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(n_decay), lr, beta1, beta2, eps,
-                                    weight_decay, int(step), float(grad_scale), _ptr(w_bf16), _ptr(grad_sumsq), float(max_norm or 0.0),
-                                    float(skip_norm or 0.0), _ptr(step_dev), _stream()), "adamw_flat")
+    # p, g, m, v in; p, m, v (and the bf16 weights) out
+    with _Timed("adamw", 0.0, "adamw_flat_kernel", nbytes=p.numel() * (28 + (2 if w_bf16 is not None else 0))):
+        _lib.check(_L().mmae_adamw_flat(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(n_decay), lr, beta1, beta2, eps,
+                                        weight_decay, int(step), float(grad_scale), _ptr(w_bf16), _ptr(grad_sumsq), float(max_norm or 0.0),
+                                        float(skip_norm or 0.0), _ptr(step_dev), _stream()), "adamw_flat")
 
 
 def sumsq(x: torch.Tensor, out: Optional[torch.Tensor] = None):

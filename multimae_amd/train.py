@@ -31,6 +31,9 @@ def init_distributed_mode(backend: str = "nccl"):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local)
+            # the step's own streams are chosen by timing idle kernels on candidates (functional.concurrent_stream): do it
+            # before the communicator exists, so the timing never runs beside a resident collective kernel
+            Fn.prepare_streams(torch.device("cuda", local), 2)
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
