@@ -4,7 +4,7 @@ ARCH  ?= gfx950
 CSRC  := multimae_amd/csrc
 OBJ   := build/obj
 SRCS  := $(wildcard $(CSRC)/*.hip)
-OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJ)/%.o,$(SRCS)) $(OBJ)/error.o
+OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJ)/%.o,$(SRCS)) $(OBJ)/error.o $(OBJ)/comm.o
 LIB   := multimae_amd/libmmae_hip.so
 FLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-variable -Wno-unused-but-set-variable
 
@@ -18,8 +18,12 @@ $(OBJ)/error.o: $(CSRC)/error.cpp include/mmae.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
+$(OBJ)/comm.o: $(CSRC)/comm.cpp include/mmae.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(FLAGS) -c $< -o $@
+
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl
 
 clean:
 	rm -rf build $(LIB)

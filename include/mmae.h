@@ -51,10 +51,11 @@ int mmae_gemm_nt(int epi, const void* A, long lda, const void* W, long ldw, int 
 
 /* Kernel choice for mmae_gemm_nt and its two siblings below: 0 = by problem size (default), 1 = always the 128x128
  * two-workgroups-per-CU kernel, 4 = persistent 128x128 (2-stage ring), 5 = 256x256 eight-wave ping-pong kernel (K a
- * multiple of 128, else as 0).  Process-wide; for tests and tuning. */
+ * multiple of 128, else as 0).  Like every *_set_* switch of this library it applies to the calling thread's later
+ * calls only; for tests and tuning. */
 void mmae_gemm_nt_set_variant(int variant);
 /* The 256x256 kernel may cut the last row panels into 128-row half tiles so that a thin last round of tiles is shared by
- * twice as many CUs (default on); 0 switches that off.  Process-wide; for tests and tuning. */
+ * twice as many CUs (default on); 0 switches that off.  Per calling thread; for tests and tuning. */
 void mmae_gemm_nt_set_half_tiles(int on);
 /* For timing the two launches of the 256x256 path separately: the calling thread's next mmae_gemm_nt calls run
  * 1 = the full-tile launch only, 2 = the half-tile launch only, 0 = both (default); other kernels ignore it.
@@ -82,7 +83,7 @@ int mmae_unpatchify_gemm(const void* A, long lda, const void* W, int M, int N, i
  * (bitwise reproducible).  If colsum_out != NULL it also receives (+)= the column sums of X (the bias
  * gradient), computed by the same kernel. */
 /* Kernel choice for mmae_gemm_tn: 0 = by problem size (default), 1 = 128x128 kernel, 2 = 256x256 eight-wave kernel.
- * Process-wide; for tests and tuning.  Set it before asking for the workspace size (the split count depends on it). */
+ * Per calling thread; for tests and tuning.  Set it before asking for the workspace size (the split count depends on it). */
 void mmae_gemm_tn_set_variant(int variant);
 int mmae_gemm_tn_last_kernel(void);
 /* For timing the two launches of mmae_gemm_tn separately: the calling thread's next calls run 1 = the split GEMM only
@@ -110,7 +111,7 @@ int mmae_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma, 
                        int rows, int dim, void* workspace, size_t workspace_bytes, mmae_stream_t stream);
 
 /* Kernel choice for mmae_layernorm_bwd: 0 = several rows per wave and pass where dim is 256, 768 or 1024 (default),
- * 1 = the generic one-row kernel everywhere.  Process-wide; for tests and tuning. */
+ * 1 = the generic one-row kernel everywhere.  Per calling thread; for tests and tuning. */
 int mmae_layernorm_bwd_set_variant(int variant);
 int mmae_layernorm_param_reduce(const void* workspace, size_t workspace_bytes, int rows, int dim, float* dgamma, float* dbeta,
                                 int accumulate, mmae_stream_t stream);
@@ -119,7 +120,9 @@ int mmae_layernorm_param_reduce(const void* workspace, size_t workspace_bytes, i
  * softmax(q k^T * scale) v per (batch, head) without materialising the scores.  q/k/v/o rows are
  * addressed as base + (b*len + i)*ld + h*head_dim, so the packed [B,N,3,H,d] qkv buffer and the
  * [B,M,2,H,d] kv buffer are read in place.  head_dim in {32, 64}.  The rows of one head that a kernel keeps in
- * LDS (K,V for fwd and the dQ kernel; Q,dO for the dK/dV kernel) must fit 160 KiB: <= 568 rows at head_dim 64.
+ * LDS (K,V for fwd and the dQ kernel; Q,dO and two floats per query for the dK/dV kernel), padded to a multiple of 32
+ * rows of head_dim + 8 elements, must fit 160 KiB: kv_len <= 544 at head_dim 64 and <= 1024 at head_dim 32 for fwd;
+ * for bwd also q_len <= 544 at head_dim 64 and <= 960 at head_dim 32.  Longer sequences return MMAE_ESHAPE.
  * fwd also writes lse[B,H,q_len] (f32, natural log) for the backward.  bwd = one kernel per (batch, head) with Q, dO, K, V
  * in LDS when two such blocks fit a CU (the pretraining lengths), else two kernels (dQ per query block; dK,dV per key
  * tile); accumulation in registers, no atomics; workspace holds rowsum(dO*O) [B,H,q_len] f32 for the two-kernel form. */
@@ -131,7 +134,7 @@ int mmae_attn_bwd(const void* q, long ldq, const void* k, long ldk, const void* 
                   long lddv, int B, int H, int q_len, int kv_len, int head_dim, float scale, void* workspace,
                   size_t workspace_bytes, mmae_stream_t stream);
 /* Kernel choice for mmae_attn_bwd: 0 = by size (default), 1 = two kernels, 2 = one kernel whenever Q, dO, K, V of a head
- * fit the 160 KiB LDS.  Process-wide; for tests and tuning. */
+ * fit the 160 KiB LDS.  Per calling thread; for tests and tuning. */
 void mmae_attn_bwd_set_variant(int variant);
 
 /* ---- masking (multimae/multimae.py:218-253) --------------------------------------------------
@@ -246,6 +249,21 @@ int mmae_transpose_multi(const void* src_bf16, void* dst_bf16, const int* table,
                          mmae_stream_t stream);
 /* y(bf16) = x(f32) elementwise */
 int mmae_cast_bf16(const float* x, void* y_bf16, long n, mmae_stream_t stream);
+/* ---- data-parallel gradient exchange over RCCL ------------------------------------------------------
+ * The reference wraps the model in DistributedDataParallel (run_pretraining_multimae.py:224-226: rank-0 parameter
+ * broadcast at construction, bucketed gradient all-reduce during backward) over torch.distributed's NCCL backend
+ * (utils/dist.py:94-107).  These entries are that exchange on raw device pointers: one communicator per process and GPU,
+ * created from a 128-byte id that rank 0 draws (mmae_comm_unique_id) and hands to the other ranks by any host channel;
+ * mmae_comm_init is collective (every rank calls it, with its GPU current); all-reduce (SUM, in place) and broadcast only
+ * enqueue on `stream`.  librccl is resolved at the first call (the copy already loaded in the process, else librccl.so). */
+#define MMAE_COMM_ID_BYTES 128
+enum { MMAE_COMM_F32 = 0, MMAE_COMM_BF16 = 1 };
+int mmae_comm_unique_id(void* id_host);
+int mmae_comm_init(const void* id_host, int rank, int world, void** handle);
+int mmae_comm_allreduce_bucket(void* handle, void* ptr, size_t count, int dtype, mmae_stream_t stream);
+int mmae_comm_broadcast(void* handle, void* ptr, size_t count, int dtype, int root, mmae_stream_t stream);
+int mmae_comm_destroy(void* handle);
+
 /* One idle workgroup for `us` microseconds on `stream` (no reference counterpart).  The host side times pairs of these on
  * two streams to learn whether the streams share a hardware queue (a process has 4; streams on one queue do not overlap). */
 int mmae_spin_us(int us, mmae_stream_t stream);

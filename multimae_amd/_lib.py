@@ -61,6 +61,11 @@ SIGNATURES = {
     "mmae_cast_transpose": (_i, [_p, _i, _i, _p, _p, _p]),
     "mmae_transpose_multi": (_i, [_p, _p, _p, _i, _i, _p]),
     "mmae_cast_bf16": (_i, [_p, _p, _l, _p]),
+    "mmae_comm_unique_id": (_i, [_p]),
+    "mmae_comm_init": (_i, [_p, _i, _i, C.POINTER(_p)]),
+    "mmae_comm_allreduce_bucket": (_i, [_p, _p, _z, _i, _p]),
+    "mmae_comm_broadcast": (_i, [_p, _p, _z, _i, _i, _p]),
+    "mmae_comm_destroy": (_i, [_p]),
     "mmae_spin_us": (_i, [_i, _p]),
 }
 

@@ -657,7 +657,7 @@ static int launch_dkv(const AttnArgs& a, hipStream_t s) {
                            a.B * a.H, NW * 64, s, a, nqp, reserved);
 }
 
-static int g_bwd_variant = 0;  // 0 = by size, 1 = two kernels, 2 = one kernel whenever the head fits LDS
+static thread_local int g_bwd_variant = 0;  // 0 = by size, 1 = two kernels, 2 = one kernel whenever the head fits LDS
 extern "C" void mmae_attn_bwd_set_variant(int v) { g_bwd_variant = v; }
 
 static size_t fused_lds_bytes(const AttnArgs& a, int D) {

@@ -767,7 +767,7 @@ static int num_cus();
 // half of the CUs.
 #define PP_HALF_COST 0.75
 struct PpPlan { int full_panels, tiles_n, halves; double rounds; };
-static int g_pp_halves = 1;  // 0 switches the half tiles off (tuning)
+static thread_local int g_pp_halves = 1;  // 0 switches the half tiles off (tuning)
 static PpPlan pp_plan(int M, int N, int K) {
     const int G = num_cus();
     const int tm = (M + 255) / 256, tn = (N + 255) / 256;
@@ -865,7 +865,7 @@ static thread_local int g_last_nt = 0, g_last_tn = 0;  // kernel chosen by this 
 extern "C" int mmae_gemm_nt_last_kernel(void) { return g_last_nt; }
 extern "C" int mmae_gemm_tn_last_kernel(void) { return g_last_tn; }
 
-static int g_nt_variant = 0;  // 0 = choose by size, 1 = 128x128 grid kernel, 4 = persistent 128x128, 5 = 256x256 ping-pong
+static thread_local int g_nt_variant = 0;  // 0 = choose by size, 1 = 128x128 grid kernel, 4 = persistent 128x128, 5 = 256x256 ping-pong
 extern "C" void mmae_gemm_nt_set_variant(int v) { g_nt_variant = v; }
 extern "C" void mmae_gemm_nt_set_half_tiles(int on) { g_pp_halves = on; }
 extern "C" void mmae_gemm_nt_set_phase(int phase) { g_nt_phase = phase; }
@@ -1334,7 +1334,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab, i
     }
 }
 
-static int g_tn_variant = 0;  // 0 = by problem size, 1 = 128x128 kernel, 2 = 256x256 ping-pong kernel
+static thread_local int g_tn_variant = 0;  // 0 = by problem size, 1 = 128x128 kernel, 2 = 256x256 ping-pong kernel
 extern "C" void mmae_gemm_tn_set_variant(int v) { g_tn_variant = v; }
 
 static bool tn_use_pp(int M, int N, int K) {

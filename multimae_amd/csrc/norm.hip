@@ -257,7 +257,7 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
 }
 
 // 0: the multi-row kernel where dim is 256 / 768 / 1024, 1: the generic one-row-per-pass kernel everywhere (for tests and timing)
-static int g_ln_bwd_variant = 0;
+static thread_local int g_ln_bwd_variant = 0;
 extern "C" int mmae_layernorm_bwd_set_variant(int v) {
     MMAE_REQUIRE(v == 0 || v == 1, MMAE_EINVAL, "layernorm_bwd_set_variant: %d is not 0 or 1", v);
     g_ln_bwd_variant = v;

@@ -87,6 +87,17 @@ def _ready(p):
         cb()
 
 
+def _deliver(p, g):
+    """Hand gradient `g` of parameter `p` over: added into the flat gradient storage here, on the stream the backward
+    kernel ran on, when the parameter lives there (the Function then returns None for it and autograd's own accumulation
+    node, which is bound to the stream of the iteration that created it, never sees a tensor); returned otherwise."""
+    if g is None or not _direct(p):
+        return g
+    p.grad.add_(g.reshape(p.grad.shape))
+    _ready(p)
+    return None
+
+
 # Weight gradients that accumulate straight into flat storage do not feed the rest of backward, so they run on a second
 # stream: their workgroups fill the CUs that the main chain's kernels leave idle in their last, partly filled round.
 SIDE_STREAM_DW = os.environ.get("MMAE_SIDE_STREAM", "1") != "0"
@@ -496,12 +507,12 @@ class EmbedFn(torch.autograd.Function):
         ops.append_global(global_tokens.detach().contiguous(), x, k)
         class_maps = [im if ce is not None else None for im, ce in zip(images, class_embs)]
         ctx.saved = (a, widths, [w.shape for w in weights], k, n_img, keep32, class_maps, weights, patches, (nh, nw),
-                     [None if ce is None else tuple(ce.shape) for ce in class_embs])
+                     [None if ce is None else tuple(ce.shape) for ce in class_embs], (global_tokens, biases, class_embs))
         return x
 
     @staticmethod
     def backward(ctx, dx):
-        a, widths, wshapes, k, n_img, keep32, class_maps, weights, patches, (nh, nw), ce_shapes = ctx.saved
+        a, widths, wshapes, k, n_img, keep32, class_maps, weights, patches, (nh, nw), ce_shapes, (global_tokens, biases, class_embs) = ctx.saved
         ctx.saved = None
         d_global, rows = ops.embed_bwd_reduce(dx.contiguous(), k)
         dwcat = ops.gemm_tn(rows, a)  # [D, ktot]: patch columns, then the one-hot(domain) columns = bias grads
@@ -519,6 +530,10 @@ class EmbedFn(torch.autograd.Function):
                 ncls, cdim = ce_shapes[t]
                 dces.append(ops.class_emb_bwd(d_rows, class_maps[t].contiguous(), keep32, t * nh * nw, nh, nw, patches[t], ncls, cdim))
             off += n
+        d_global = _deliver(global_tokens, d_global)
+        dws = [_deliver(w, d) for w, d in zip(weights, dws)]
+        dbs = [_deliver(b_, d) for b_, d in zip(biases, dbs)]
+        dces = [_deliver(ce, d) for ce, d in zip(class_embs, dces)]
         return (None, None, None, None, d_global, None, *([None] * n_img), *dws, *dbs, *dces)
 
 
@@ -551,14 +566,14 @@ class DecoderHeadFn(torch.autograd.Function):
         x = ops.gemm_nt(ops.EPI_F32, o, wpr, pr_b)  # the cross-attention output replaces the queries (no residual)
         y, s_mlp = _mlp_fwd(x, on_w, on_b, f1w, f1b, f2w, f2b)
         ctx.saved = (s_mlp, o, lse, q, kv, qn, cn, queries, context, qmean, qrstd, cmean, crstd, enc_b,
-                     wqt, wkvt, wprt, wpct, keep32, restore32, meta, (B, seq, D, Dd), [e is not None for e in task_embs],
+                     wqt, wkvt, wprt, wpct, keep32, restore32, meta, (B, seq, D, Dd), (mask_token, task_embs),
                      (pc_w, pc_b, qn_w, qn_b, cn_w, cn_b, q_w, q_b, kv_w, kv_b, pr_w, pr_b))
         return y.reshape(B, ntok, Dd)
 
     @staticmethod
     def backward(ctx, g):
         (s_mlp, o, lse, q, kv, qn, cn, queries, context, qmean, qrstd, cmean, crstd, enc_b,
-         wqt, wkvt, wprt, wpct, keep32, restore32, meta, dims, task_present,
+         wqt, wkvt, wprt, wpct, keep32, restore32, meta, dims, (mask_token, task_embs),
          (pc_w, pc_b, qn_w, qn_b, cn_w, cn_b, q_w, q_b, kv_w, kv_b, pr_w, pr_b)) = ctx.saved
         ctx.saved = None
         heads, k, G, T, ntok, q_start = meta
@@ -583,8 +598,10 @@ class DecoderHeadFn(torch.autograd.Function):
         d_enc = ops.gemm_nt(ops.EPI_F32, d_ctx2, wpct, None).reshape(B, seq, D)
         dwpc, dbpc = _lin_grads(d_ctx2, enc_b, pc_w, pc_b)
         dnw, dnb, df1w, df1b, df2w, df2b = g_mlp
+        d_mask = _deliver(mask_token, d_mask)
+        d_task = [None if e is None else _deliver(e, d) for d, e in zip(d_task, task_embs)]
         return (d_enc, None, None, None, None, d_mask, dwpc, dbpc, dqnw, dqnb, dcnw, dcnb, dwq, dbq, dwkv, dbkv, dwpr, dbpr,
-                dnw, dnb, df1w, df1b, df2w, df2b, *[d if present else None for d, present in zip(d_task, task_present)])
+                dnw, dnb, df1w, df1b, df2w, df2b, *d_task)
 
 
 class OutProjFn(torch.autograd.Function):

@@ -146,10 +146,20 @@ class GradBuckets:
     `no_sync` = True suspends the exchange for gradient accumulation: hooks return at once and gradients keep
     accumulating locally; the first backward after it is cleared all-reduces the accumulated sums."""
 
-    def __init__(self, flat: FlatParams, bucket_mb: float = 64.0, group=None, broadcast: bool = True):
+    def __init__(self, flat: FlatParams, bucket_mb: float = 64.0, group=None, broadcast: bool = True, comm=None):
+        """comm: None = collectives through torch.distributed (backend "nccl" is RCCL), or a multimae_amd.comm.NativeComm
+        (the C ABI's RCCL driver: all-reduces enqueued on the communicator's own stream, ordered against the step's
+        streams by events, no host-side work objects).  MMAE_COMM=native in the environment builds one."""
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.no_sync = False
+        single = os.environ.get("MMAE_DP_SINGLE_RANK") == "1"
+        if comm is None and os.environ.get("MMAE_COMM") == "native" and flat.params.is_cuda and (self.world > 1 or single):
+            from .comm import NativeComm
+            comm = NativeComm(group=group)
+        self.comm = comm
+        if comm is not None:
+            self.world = comm.world
         if broadcast and self.world > 1:
             self.broadcast_parameters()
         cap = int(bucket_mb * (1 << 20) / 4)
@@ -180,7 +190,7 @@ class GradBuckets:
         self.signalled = [False] * len(flat.named)
         self.works = []
         # a one-rank group still runs the collectives when asked to (MMAE_DP_SINGLE_RANK=1: exercises the RCCL path on one GPU)
-        self.enabled = self.world > 1 or (dist.is_initialized() and os.environ.get("MMAE_DP_SINGLE_RANK") == "1")
+        self.enabled = self.world > 1 or ((dist.is_initialized() or self.comm is not None) and single)
         if self.enabled:
             for i, (_, p) in enumerate(flat.named):
                 hook = self._make_hook(i)
@@ -189,11 +199,25 @@ class GradBuckets:
 
     def broadcast_parameters(self, src: int = 0):
         """Every rank takes rank `src`'s parameters and buffers; the bf16 weight copies are rebuilt from them."""
-        src_global = dist.get_global_rank(self.group, src) if self.group is not None else src
         with torch.no_grad():
-            dist.broadcast(self.flat.params, src=src_global, group=self.group)
-            for t in self.flat.frozen:
-                dist.broadcast(t.data, src=src_global, group=self.group)
+            if self.comm is not None:
+                cur = torch.cuda.current_stream(self.flat.params.device)
+                self.comm.stream.wait_stream(cur)
+                for t in [self.flat.params] + [f.data for f in self.flat.frozen]:
+                    if t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous():
+                        self.comm.broadcast_(t, root=src)
+                    else:  # other dtypes / layouts: through a float32 copy
+                        tmp = t.to(torch.float32).contiguous()
+                        self.comm.broadcast_(tmp, root=src)
+                        tmp.record_stream(self.comm.stream)
+                        with torch.cuda.stream(self.comm.stream):
+                            t.copy_(tmp)
+                cur.wait_stream(self.comm.stream)
+            else:
+                src_global = dist.get_global_rank(self.group, src) if self.group is not None else src
+                dist.broadcast(self.flat.params, src=src_global, group=self.group)
+                for t in self.flat.frozen:
+                    dist.broadcast(t.data, src=src_global, group=self.group)
         self.flat.sync_bf16()
 
     def _make_hook(self, i):
@@ -219,6 +243,15 @@ class GradBuckets:
         if buf.is_cuda:  # kernels of several decoder streams may have written into this bucket
             Fn.join_aux_streams(buf.device, reset=False)
         side = Fn.side_stream_pending(buf.device) if buf.is_cuda else None
+        if self.comm is not None:
+            # ordered after everything queued so far on the streams that write gradients, and enqueued on the communicator's
+            # own stream: the host neither waits nor keeps a handle per collective
+            self.comm.stream.wait_stream(torch.cuda.current_stream(buf.device))
+            if side is not None:
+                self.comm.stream.wait_stream(side)
+            self.comm.all_reduce_(buf)
+            self._comm_pending = True
+            return
         # gloo stages device tensors through the host; several of those in flight on one device have stalled (seen with two
         # ranks sharing a GPU), so each is finished before the next is issued.  RCCL stays asynchronous.
         serial = buf.is_cuda and dist.get_backend(self.group) == "gloo"
@@ -243,6 +276,9 @@ class GradBuckets:
         for w in self.works:
             w.wait()
         self.works = []
+        if self.comm is not None and getattr(self, "_comm_pending", False):
+            torch.cuda.current_stream(self.flat.grads.device).wait_stream(self.comm.stream)
+            self._comm_pending = False
         self.pending = [b[2] for b in self.buckets]
         self.signalled = [False] * len(self.signalled)
 

@@ -222,6 +222,37 @@ def test_attention_fwd_bwd(ops, attn_bwd_variant, B, H, Nq, Nk, d):
     assert rel_err(dv.float(), back(v4, Nk)) < BF16_TOL
 
 
+def test_attention_length_limit(ops):
+    """The keys (forward, dQ) or queries (dK/dV) of one head live in LDS: the longest sequences that fit 160 KiB run and
+    agree with the reference, one 32-row tile more returns MMAE_ESHAPE before anything is launched."""
+    from multimae_amd import _lib
+    for d, n_ok in ((64, 544), (32, 960)):
+        B, H = 1, 2
+        qkv = _randn(B * n_ok, 3 * H * d, seed=30)
+        q, k, v = qkv[:, :H * d], qkv[:, H * d:2 * H * d], qkv[:, 2 * H * d:]
+        o, lse = ops.attn_fwd(q, k, v, B, H, n_ok, n_ok, d, d ** -0.5)
+        f = lambda t, n=n_ok: t.float().reshape(B, n, H, d).permute(0, 2, 1, 3)
+        oref, lref = _attn_ref(f(q), f(k), f(v), d ** -0.5)
+        assert rel_err(f(o), oref) < 6e-3 and rel_err(lse, lref) < 1e-4
+        dqkv = torch.zeros_like(qkv)
+        ops.attn_bwd(q, k, v, o, _randn(B * n_ok, H * d, seed=31), lse, dqkv[:, :H * d], dqkv[:, H * d:2 * H * d], dqkv[:, 2 * H * d:],
+                     B, H, n_ok, n_ok, d, d ** -0.5)
+        assert torch.isfinite(dqkv.float()).all() and dqkv.float().abs().sum() > 0
+        n_bad = (1153 if d == 64 else 1025)  # ViT-L/16 384^2 without masking at head_dim 64; one row past 1024 at head_dim 32
+        big = _randn(B * n_bad, 3 * H * d, seed=32)
+        qb, kb, vb = big[:, :H * d], big[:, H * d:2 * H * d], big[:, 2 * H * d:]
+        with pytest.raises(_lib.MmaeError, match="LDS"):
+            ops.attn_fwd(qb, kb, vb, B, H, n_bad, n_bad, d, d ** -0.5)
+        ob, lb = torch.zeros(B * n_bad, H * d, dtype=torch.bfloat16, device="cuda"), torch.zeros(B, H, n_bad, device="cuda")
+        with pytest.raises(_lib.MmaeError, match="LDS"):
+            ops.attn_bwd(qb, kb, vb, ob, ob, lb, torch.zeros_like(qb), torch.zeros_like(kb), torch.zeros_like(vb), B, H, n_bad, n_bad, d,
+                         d ** -0.5)
+    # just past the limit at head_dim 64 (576 rows, the next multiple of 32 after 544)
+    qkv = _randn(576, 3 * 64, seed=33)
+    with pytest.raises(_lib.MmaeError, match="LDS"):
+        ops.attn_fwd(qkv[:, :64], qkv[:, 64:128], qkv[:, 128:], 1, 1, 576, 576, 64, 0.125)
+
+
 def test_attention_spiked_scores(ops):
     # one key dominates each row (large logits): softmax must not overflow and the padded key tile must stay masked
     B, H, N, d = 1, 2, 99, 64
