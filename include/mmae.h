@@ -212,6 +212,17 @@ int mmae_masked_loss(int kind, int norm_pix, const void* pred, int pred_is_bf16,
                      int B, int C, int H, int W, int patch, float* loss, void* d_pred, void* workspace,
                      size_t workspace_bytes, mmae_stream_t stream);
 
+/* mmae_masked_loss without a workspace, for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The per-sample mask counts and
+ * per-patch-row partial sums (B * (1 + H / patch) floats) live in a fixed array of MMAE_MASKED_LOSS_STATIC_BYTES inside the
+ * library's device image, one copy per GPU, held until the process ends; larger inputs return MMAE_EWORKSPACE.  The call
+ * allocates and frees nothing and enqueues the same kernels as mmae_masked_loss, so results are bitwise the same.  Calls
+ * on one GPU share the array: calls that overlap (different streams without an ordering between them) race. */
+#define MMAE_MASKED_LOSS_STATIC_BYTES 262144
+int mmae_masked_loss_static(int kind, int norm_pix, const void* pred, int pred_is_bf16, const float* target,
+                            const int64_t* mask, int B, int C, int H, int W, int patch, float* loss, void* d_pred,
+                            mmae_stream_t stream);
+
 /* Masked cross entropy over a class map (multimae/criterion.py:39-65): logits bf16 or f32 [B,C,H,W], target i64 [B,H,W]
  * (-100 = ignored pixel), mask i64 [B, (H/patch)*(W/patch)] or NULL (plain mean), patch = patch_size / stride.
  * Writes the f32 scalar loss and, if d_logits != NULL, its gradient in the logits' dtype. */

@@ -55,6 +55,7 @@ SIGNATURES = {
     "mmae_masked_ce_workspace_bytes": (_z, [_i, _i, _i]),
     "mmae_masked_ce": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _z, _p]),
     "mmae_masked_loss": (_i, [_i, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
+    "mmae_masked_loss_static": (_i, [_i, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "mmae_standardize_depth": (_i, [_p, _p, _i, _l, C.c_double, C.c_double, _f, _p]),
     "mmae_adamw_flat": (_i, [_p, _p, _p, _p, _l, _l, _f, _f, _f, _f, _f, _i, _f, _p, _p, _f, _f, _p, _p]),
     "mmae_sumsq": (_i, [_p, _l, _p, _p, _z, _p]),

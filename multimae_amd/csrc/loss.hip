@@ -6,6 +6,7 @@
 //   loss   = mean of loss_b over the samples with nmask_b > 0 (nanmean); 0 if no token is masked at all
 //   d_pred = mask * err' / (C * P*P * nmask_b * nvalid)      (NaN for a sample with nmask_b == 0, as in the reference)
 #include "common.h"
+#include <mutex>
 
 struct LossArgs {
     const void* pred; const float* target; const int64_t* mask;
@@ -163,19 +164,14 @@ extern "C" size_t mmae_masked_loss_workspace_bytes(int B, int C, int H, int W, i
     return (size_t)B * sizeof(float) * (1 + (size_t)(H / (patch > 0 ? patch : 1)));
 }
 
-extern "C" int mmae_masked_loss(int kind, int norm_pix, const void* pred, int pred_is_bf16, const float* target,
-                                const int64_t* mask, int B, int C, int H, int W, int patch, float* loss, void* d_pred,
-                                void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    MMAE_REQUIRE(pred && target && loss && workspace, MMAE_EINVAL, "masked_loss: null pointer");
-    MMAE_REQUIRE(kind == 0 || kind == 1, MMAE_EINVAL, "masked_loss: kind %d not in {0 (MSE), 1 (L1)}", kind);
-    MMAE_REQUIRE(B > 0 && C > 0 && patch >= 4 && patch % 4 == 0 && H % patch == 0 && W % patch == 0, MMAE_ESHAPE,
-                 "masked_loss: image %dx%d must be a multiple of the patch %d (itself a multiple of 4)", H, W, patch);
-    MMAE_REQUIRE(W / 4 <= 1024 && W / patch <= 64, MMAE_ESHAPE, "masked_loss: width %d too large", W);
-    MMAE_REQUIRE(workspace_bytes >= mmae_masked_loss_workspace_bytes(B, C, H, W, patch), MMAE_EWORKSPACE, "masked_loss: workspace too small");
+// Argument checks and the three launches shared by the two entry points; `ws` holds B * (1 + H / patch) floats.
+static int masked_loss_launch(int kind, int norm_pix, const void* pred, int pred_is_bf16, const float* target,
+                              const int64_t* mask, int B, int C, int H, int W, int patch, float* loss, void* d_pred,
+                              float* ws, hipStream_t stream) {
     LossArgs a = {};
     a.pred = pred; a.target = target; a.mask = mask; a.B = B; a.C = C; a.H = H; a.W = W; a.P = patch;
     a.nh = H / patch; a.nw = W / patch; a.kind = kind; a.norm_pix = norm_pix; a.pred_bf16 = pred_is_bf16;
-    a.nmask = (float*)workspace; a.perr = a.nmask + B; a.loss = loss; a.d_pred = d_pred;
+    a.nmask = ws; a.perr = a.nmask + B; a.loss = loss; a.d_pred = d_pred;
     hipLaunchKernelGGL(loss_count_kernel, dim3(B), dim3(64), 0, stream, a);
     MMAE_CHECK_LAUNCH("loss_count");
     const int qx = W / 4;
@@ -186,6 +182,69 @@ extern "C" int mmae_masked_loss(int kind, int norm_pix, const void* pred, int pr
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, stream, a);
     MMAE_CHECK_LAUNCH("loss_final");
     return MMAE_OK;
+}
+
+#define MASKED_LOSS_CHECK_ARGS(name)                                                                                         \
+    MMAE_REQUIRE(pred && target && loss, MMAE_EINVAL, name ": null pointer");                                                 \
+    MMAE_REQUIRE(kind == 0 || kind == 1, MMAE_EINVAL, name ": kind %d not in {0 (MSE), 1 (L1)}", kind);                       \
+    MMAE_REQUIRE(B > 0 && C > 0 && patch >= 4 && patch % 4 == 0 && H % patch == 0 && W % patch == 0, MMAE_ESHAPE,             \
+                 name ": image %dx%d must be a multiple of the patch %d (itself a multiple of 4)", H, W, patch);              \
+    MMAE_REQUIRE(W / 4 <= 1024 && W / patch <= 64, MMAE_ESHAPE, name ": width %d too large", W)
+
+extern "C" int mmae_masked_loss(int kind, int norm_pix, const void* pred, int pred_is_bf16, const float* target,
+                                const int64_t* mask, int B, int C, int H, int W, int patch, float* loss, void* d_pred,
+                                void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    MASKED_LOSS_CHECK_ARGS("masked_loss");
+    MMAE_REQUIRE(workspace, MMAE_EINVAL, "masked_loss: null pointer");
+    MMAE_REQUIRE(workspace_bytes >= mmae_masked_loss_workspace_bytes(B, C, H, W, patch), MMAE_EWORKSPACE, "masked_loss: workspace too small");
+    return masked_loss_launch(kind, norm_pix, pred, pred_is_bf16, target, mask, B, C, H, W, patch, loss, d_pred,
+                              (float*)workspace, stream);
+}
+
+// The same loss for callers that cannot allocate (HIP graph capture, serving loops): the per-sample mask counts and the
+// per-patch-row partial sums live in a fixed array in the library's own device memory instead of a caller workspace.
+// Every GPU holds its own copy of the array; host code reaches it only through the address hipGetSymbolAddress returns
+// for the current device (the array's name is not a device address on the host side).  The kernels overwrite every entry
+// they later read, so nothing needs clearing between calls; two calls in flight on one GPU share the array and race.
+#define MMAE_LOSS_STATIC_FLOATS (MMAE_MASKED_LOSS_STATIC_BYTES / 4)  /* B * (1 + H / patch) floats, e.g. 2048 images of 24 patch rows */
+#ifndef MMAE_MASKED_LOSS_STATIC_BYTES
+#error "include/mmae.h must define MMAE_MASKED_LOSS_STATIC_BYTES"
+#endif
+static __device__ __align__(256) float scratch[MMAE_LOSS_STATIC_FLOATS];
+
+#define MMAE_MAX_DEVICES 64
+static float* g_scratch_ptr[MMAE_MAX_DEVICES];  // per device; written once under the mutex
+static std::mutex g_scratch_mutex;
+
+static int static_scratch(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    MMAE_REQUIRE(e == hipSuccess && dev >= 0 && dev < MMAE_MAX_DEVICES, MMAE_EINVAL, "masked_loss_static: no current device (%s)",
+                 hipGetErrorString(e));
+    std::lock_guard<std::mutex> guard(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        MMAE_REQUIRE(e == hipSuccess && p, MMAE_ELAUNCH, "masked_loss_static: hipGetSymbolAddress failed on device %d: %s", dev,
+                     hipGetErrorString(e));
+        g_scratch_ptr[dev] = (float*)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return MMAE_OK;
+}
+
+extern "C" int mmae_masked_loss_static(int kind, int norm_pix, const void* pred, int pred_is_bf16, const float* target,
+                                       const int64_t* mask, int B, int C, int H, int W, int patch, float* loss, void* d_pred,
+                                       hipStream_t stream) {
+    MASKED_LOSS_CHECK_ARGS("masked_loss_static");
+    const size_t need = mmae_masked_loss_workspace_bytes(B, C, H, W, patch);
+    MMAE_REQUIRE(need <= sizeof(float) * MMAE_LOSS_STATIC_FLOATS, MMAE_EWORKSPACE,
+                 "masked_loss_static: %d images x %d patch rows need %zu bytes of partial sums, the fixed array holds %zu "
+                 "(use mmae_masked_loss with a workspace)", B, H / patch, need, sizeof(float) * MMAE_LOSS_STATIC_FLOATS);
+    float* ws = nullptr;
+    const int rc = static_scratch(&ws);
+    if (rc != MMAE_OK) return rc;
+    return masked_loss_launch(kind, norm_pix, pred, pred_is_bf16, target, mask, B, C, H, W, patch, loss, d_pred, ws, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
