@@ -180,7 +180,7 @@ def main():
     elapsed = time.perf_counter() - t0
     note("timed steps done")
     if dist.is_initialized():
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.item())

@@ -16,7 +16,7 @@ _DTYPES = {torch.float32: 0, torch.bfloat16: 1}
 
 
 class NativeComm:
-    """One RCCL communicator for this process's current GPU plus a dedicated high-priority stream for its collectives."""
+    """One RCCL communicator for this process's current GPU plus a dedicated stream for its collectives."""
 
     def __init__(self, rank: Optional[int] = None, world: Optional[int] = None, group=None):
         lib = _lib.load()
@@ -40,7 +40,10 @@ class NativeComm:
         handle = C.c_void_p()
         _lib.check(lib.mmae_comm_init(ident, self.rank, self.world, C.byref(handle)), "comm_init")
         self._lib, self._handle = lib, handle
-        self.stream = torch.cuda.Stream(priority=-1)
+        # An ordinary-priority stream on purpose.  On this ROCm stack a high-priority stream that waits on events recorded
+        # on ordinary streams of the same process can stop every queue of the process for good (scripts/prio_inversion.py
+        # shows it with idle kernels alone), and the collectives here wait on the step's compute streams by events.
+        self.stream = torch.cuda.Stream()
 
     def all_reduce_(self, t: torch.Tensor, stream: Optional[torch.cuda.Stream] = None):
         """In-place SUM over the ranks, enqueued on `stream` (default: the communicator's own stream)."""

@@ -29,14 +29,19 @@ def init_distributed_mode(backend: str = "nccl"):
     if (world > 1 or single) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        native = os.environ.get("MMAE_COMM") == "native"
         if backend == "nccl":
             torch.cuda.set_device(local)
             # the step's own streams are chosen by timing idle kernels on candidates (functional.concurrent_stream): do it
             # before the communicator exists, so the timing never runs beside a resident collective kernel
             Fn.prepare_streams(torch.device("cuda", local), 2)
+        if backend == "nccl" and not native:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            # With the C ABI's RCCL driver (MMAE_COMM=native) torch.distributed is the host-side control plane only (the
+            # communicator id, barriers, scalars): gloo.  The driver's communicator then is the only RCCL communicator of
+            # the process; beside a second one (torch's "nccl" group on the same GPU) a barrier was seen to hang.
+            dist.init_process_group(backend="gloo" if backend == "nccl" else backend, rank=rank, world_size=world)
         dist.barrier()
     return rank, world, local
 
@@ -252,8 +257,10 @@ class GradBuckets:
             self.comm.all_reduce_(buf)
             self._comm_pending = True
             return
-        # gloo stages device tensors through the host; several of those in flight on one device have stalled (seen with two
-        # ranks sharing a GPU), so each is finished before the next is issued.  RCCL stays asynchronous.
+        # gloo (a rehearsal backend here: several ranks on one GPU) copies device tensors to the host on high-priority streams
+        # of its own that wait on this step's streams by events; such waits can stop the process's queues for good on this
+        # ROCm stack (scripts/prio_inversion.py), the more likely the more work is pending, so each gloo collective on
+        # device tensors is finished before more work is queued.  RCCL (ordinary-priority streams) stays asynchronous.
         serial = buf.is_cuda and dist.get_backend(self.group) == "gloo"
         if side is None:
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

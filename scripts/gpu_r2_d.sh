@@ -1,0 +1,13 @@
+#!/bin/bash
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/r2d
+mkdir -p $OUT
+cd $R
+echo "decoder cost" > $OUT/progress.txt
+timeout -k 10 300 python3 scripts/decoder_cost.py > $OUT/decoder_cost.log 2>&1 || { tail -20 $OUT/decoder_cost.log; exit 1; }
+cat $OUT/decoder_cost.log | grep streams
+echo "bench native comm one rank" >> $OUT/progress.txt
+MMAE_BENCH_VERBOSE=1 MMAE_DP_SINGLE_RANK=1 MMAE_COMM=native timeout -k 10 100 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $OUT/b_native.json 2> $OUT/b_native.err || { tail -40 $OUT/b_native.err; exit 1; }
+cut -c1-300 $OUT/b_native.json
+echo "done" >> $OUT/progress.txt

@@ -189,7 +189,10 @@ def test_native_rccl_driver_with_a_one_rank_communicator(tmp_path):
 def test_two_rank_step_equals_single_rank_on_identical_batches(tmp_path):
     """Both ranks see the same batch and masks and, after the start-up broadcast, hold rank 0's weights, so the averaged
     gradient is the single-rank gradient: (g + g) / 2 == g exactly, and two optimizer steps must land on bitwise identical
-    parameters.  The ranks run the step with its default streams (weight gradients and decoders on their own)."""
+    parameters.  The ranks run the step with its default streams (weight gradients and decoders on their own).
+    (Earlier stalls of this test were gloo's: its device path waits on the step's streams from high-priority streams, which
+    can stop a process's queues on this ROCm stack, see scripts/prio_inversion.py; GradBuckets finishes each gloo
+    collective before queueing more work.  A stall is reported with both ranks' stacks.)"""
     out = str(tmp_path / "dp.pt")
     port = 29700 + os.getpid() % 200
     ctx = mp.spawn(_worker, args=(2, port, out), nprocs=2, join=False)
