@@ -51,7 +51,7 @@ int mmae_gemm_nt(int epi, const void* A, long lda, const void* W, long ldw, int 
 
 /* Kernel choice for mmae_gemm_nt and its two siblings below: 0 = by problem size (default), 1 = always the 128x128
  * two-workgroups-per-CU kernel, 4 = persistent 128x128 (2-stage ring), 5 = 256x256 eight-wave ping-pong kernel (K a
- * multiple of 128, else as 0).  Like every *_set_* switch of this library it applies to the calling thread's later
+ * multiple of 128, else as 0), 7 = 128x256 four-wave kernel, two workgroups per CU (K a multiple of 64, else as 0).  Like every *_set_* switch of this library it applies to the calling thread's later
  * calls only; for tests and tuning. */
 void mmae_gemm_nt_set_variant(int variant);
 /* The 256x256 kernel may cut the last row panels into 128-row half tiles so that a thin last round of tiles is shared by

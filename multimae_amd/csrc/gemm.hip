@@ -859,6 +859,301 @@ static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
     return MMAE_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// 128x256x64 persistent kernel, four waves (each 128 rows x 64 columns = 128 accumulator registers, the wave tile of the
+// 256x256 kernel), TWO workgroups per CU.  The 256x256 kernel keeps one workgroup per CU, so while its eight waves store a
+// tile the matrix cores of the CU idle (a quarter to a half of the tile time for the epilogues that move a second large
+// matrix).  Here the two workgroups of a CU are independent: one stores while the other multiplies, and the per-SIMD
+// pairing "one wave reads LDS / loads, the other runs its MFMA cluster" comes from the hardware arbiter instead of a
+// barrier protocol.  Price: 48 KB of operands per k-tile for a 128x256 tile against 64 KB for 256x256 (1.5x the L2 -> LDS
+// bytes per FLOP).
+// LDS per workgroup (<= 80 KiB so two fit): a ring of three 8-KiB activation slots (64 rows x 128 B) and a ring of three
+// 16-KiB weight slots (4 waves x 32 rows); k-tile T uses activation slots 2T, 2T+1 (rows 0-63, 64-127) and weight slots
+// 2T, 2T+1 (columns 0-31, 32-63 of every wave's 64) modulo 3.  A k-tile is four phases as in the 256x256 kernel:
+//   phase 0: read A-lo(T), W-lo(T)                          -> quadrant (A-lo, W-lo)
+//   phase 1: read W-hi(T);  refill: A-hi(T+1), W-hi(T+1)    -> (A-lo, W-hi)        (slots read in phase 0)
+//   phase 2: read A-hi(T);  refill: W-lo(T+2)               -> (A-hi, W-hi)        (slot read in phase 1)
+//   phase 3:                refill: A-lo(T+2)               -> (A-hi, W-lo)        (slot read in phase 2)
+// one s_barrier per phase: a slot is refilled in the phase after the one that read it, and read in a phase after the
+// counted vmcnt of every wave says its copy has landed (12 copy instructions per thread and k-tile: 2 per activation
+// slot, 4 per weight slot; in-order completion).  The ring runs on across tile boundaries.
+// ------------------------------------------------------------------------------------------
+#define P2_A_BYTES 8192
+#define P2_W_BYTES 16384
+#define P2_LDS (3 * P2_A_BYTES + 3 * P2_W_BYTES + 4 * 256)  // + per-wave bias slice (64 floats)
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_p2_kernel(GemmNT p, int tiles_m, int tiles_n, int delay_ticks) {
+    extern __shared__ __attribute__((aligned(16))) char p2smem[];
+    // The second half of the grid (the workgroups that land beside the first half, one per CU) starts late, so that the two
+    // workgroups of a CU reach their epilogues at different times: started together they would do identical work in
+    // lockstep and store together, which is what this kernel exists to avoid.  Time-bounded wait on the constant-rate clock.
+    if (delay_ticks > 0 && blockIdx.x >= (gridDim.x >> 1)) {
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < delay_ticks) __builtin_amdgcn_s_sleep(8);
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave;
+    const int fr = lane & 15, fq = lane >> 4, swz = fr >> 1;
+    const int ntiles = tiles_m * tiles_n, G = gridDim.x;
+    const int me = xcd_remap(blockIdx.x, G);
+    const int nk = p.K >> 6;
+    if (me >= ntiles) return;
+    const int my_tiles = (ntiles - 1 - me) / G + 1;
+    const int total_kt = my_tiles * nk;
+    char* const a_ring = p2smem;
+    char* const w_ring = p2smem + 3 * P2_A_BYTES;
+    float* bias_lds = (float*)(p2smem + 3 * P2_A_BYTES + 3 * P2_W_BYTES) + wave * 64;
+
+    auto tile_origin = [&](int t, int& m0, int& n0) {  // groups of 8 row-tiles x all column-tiles, rows fastest
+        const int per_group = 8 * tiles_n;
+        const int grp = t / per_group, within = t - grp * per_group;
+        int rows = tiles_m - grp * 8; rows = rows < 8 ? rows : 8;
+        m0 = (grp * 8 + within % rows) * 128;
+        n0 = (within / rows) * 256;
+    };
+
+    // ---- copy cursors: 0 = A-lo, 1 = A-hi (2 instructions per thread), 2 = W-lo, 3 = W-hi (4 per thread) ----
+    const bf16* asrc[2][2];
+    const bf16* wsrc[2][4];
+    int c_kt[4], c_tile[4], c_slot[4];
+    auto set_cursor = [&](auto cur_c, int t) {
+        constexpr int c = decltype(cur_c)::value;
+        int m0, n0;
+        tile_origin(t, m0, n0);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));  // recomputed at every tile change instead of living in registers across the main loop
+        if constexpr (c < 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = (j * 4 + wave) * 8 + (ln >> 3);
+                int g = m0 + c * 64 + r;
+                g = g < p.M ? g : p.M - 1;
+                asrc[c][j] = p.A + (long)g * p.lda + (((ln & 7) ^ ((r >> 1) & 7)) << 3);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = (j * 4 + wave) * 8 + (ln >> 3);
+                int g = n0 + (r >> 5) * 64 + (c - 2) * 32 + (r & 31);
+                g = g < p.N ? g : p.N - 1;
+                wsrc[c - 2][j] = p.W + (long)g * p.ldw + (((ln & 7) ^ (((r >> 1) & 1) | (((r >> 3) & 3) << 1))) << 3);
+            }
+        }
+    };
+    auto issue = [&](auto cur_c) {  // copy the cursor's next k-tile into its ring slot, then advance the cursor
+        constexpr int c = decltype(cur_c)::value;
+        if constexpr (c < 2) {
+            char* dst = a_ring + c_slot[c] * P2_A_BYTES + wave * 1024;
+            glds16(asrc[c][0], dst);
+            glds16(asrc[c][1], dst + 4 * 1024);
+        } else {
+            char* dst = w_ring + c_slot[c] * P2_W_BYTES + wave * 1024;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds16(wsrc[c - 2][j], dst + j * 4 * 1024);
+        }
+        c_slot[c] = c_slot[c] == 0 ? 2 : c_slot[c] - 1;  // + 2 modulo 3
+        if (c_tile[c] < ntiles) {
+            if constexpr (c < 2) { asrc[c][0] += 64; asrc[c][1] += 64; }
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wsrc[c - 2][j] += 64;
+            }
+            if (++c_kt[c] == nk) {
+                c_kt[c] = 0;
+                c_tile[c] += G;
+                if (c_tile[c] < ntiles) {
+                    set_cursor(cur_c, c_tile[c]);
+                } else {  // end of this workgroup's stream: the run-ahead copies read the zero page (never consumed)
+                    if constexpr (c < 2) { asrc[c][0] = asrc[c][1] = (const bf16*)g_zero_page; }
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) wsrc[c - 2][j] = (const bf16*)g_zero_page;
+                    }
+                }
+            }
+        }
+    };
+    using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { c_kt[c] = 0; c_tile[c] = me; }
+    c_slot[0] = 0; c_slot[1] = 1; c_slot[2] = 0; c_slot[3] = 1;
+    set_cursor(C0{}, me); set_cursor(C1{}, me); set_cursor(C2{}, me); set_cursor(C3{}, me);
+
+    // ---- prologue, in the order the main loop issues: W-lo(0) A-lo(0) | A-hi(0) W-hi(0) | W-lo(1) | A-lo(1) ----
+    issue(C2{}); issue(C0{}); issue(C1{}); issue(C3{}); issue(C2{}); issue(C0{});
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // everything but the 12 newest instructions: W-lo(0), A-lo(0) landed
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 acc[2][4][4];  // [A half][weight fragment][activation fragment]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 af[4][2], wlo[2][2], whi[2][2];
+    const int a_off = fr * 128;                                             // + mi * 2048
+    const int w_off = (wn * 32 + 8 * (fr >> 2) + (fr & 3)) * 128;           // + t * 512
+    const int ch0 = ((fq ^ swz) << 4), ch1 = (((4 + fq) ^ swz) << 4);
+    auto read_a = [&](const char* slot) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            af[mi][0] = *(const bf16x8*)(slot + a_off + mi * 2048 + ch0);
+            af[mi][1] = *(const bf16x8*)(slot + a_off + mi * 2048 + ch1);
+        }
+    };
+    auto read_w = [&](const char* slot, bf16x8 (&w)[2][2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            w[t][0] = *(const bf16x8*)(slot + w_off + t * 512 + ch0);
+            w[t][1] = *(const bf16x8*)(slot + w_off + t * 512 + ch1);
+        }
+    };
+    auto mfma_quad = [&](f32x4 (&c)[4][4], int nbase, const bf16x8 (&w)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    c[nbase + t][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[t][ks], af[mi][ks], c[nbase + t][mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    int tile = me, kt = 0;
+    int ra = 0, rw = 0;  // ring slots of A-lo(T) / W-lo(T); the -hi slots are the next ones
+    for (int T = 0; T < total_kt; ++T) {
+        const int ra1 = ra == 2 ? 0 : ra + 1, rw1 = rw == 2 ? 0 : rw + 1;
+        // ---- phase 0 ----
+        read_a(a_ring + ra * P2_A_BYTES);
+        read_w(w_ring + rw * P2_W_BYTES, wlo);
+        if (kt == 0 && p.bias) {  // this tile's bias slice for the wave (256 B)
+            int m0, n0;
+            tile_origin(tile, m0, n0);
+            int n = n0 + wn * 64 + lane; n = n < p.N ? n : p.N - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + n),
+                                             (__attribute__((address_space(3))) void*)bias_lds, 4, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_quad(acc[0], 0, wlo);
+        // W-hi(T) (and the older A-hi(T)) have landed once at most the copies issued after them are in flight:
+        // W-lo(T+1) (4), A-lo(T+1) (2), and possibly this phase's bias copy
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 1 ----
+        issue(C1{});  // A-hi(T+1) -> the slot A-lo(T) was read from
+        issue(C3{});  // W-hi(T+1) -> the slot W-lo(T) was read from
+        read_w(w_ring + rw1 * P2_W_BYTES, whi);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_quad(acc[0], 2, whi);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2 ----
+        issue(C2{});  // W-lo(T+2) -> the slot W-hi(T) was read from
+        read_a(a_ring + ra1 * P2_A_BYTES);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_quad(acc[1], 2, whi);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 3 ----
+        issue(C0{});  // A-lo(T+2) -> the slot A-hi(T) was read from
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_quad(acc[1], 0, wlo);
+        ra = ra == 0 ? 2 : ra - 1;
+        rw = rw == 0 ? 2 : rw - 1;
+        if (++kt == nk) {
+            int m0, n0;
+            tile_origin(tile, m0, n0);
+            float bv[16];
+            if (p.bias) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const f32x4 b0 = *(const f32x4*)(bias_lds + 32 * u + 8 * fq), b1 = *(const f32x4*)(bias_lds + 32 * u + 8 * fq + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bv[8 * u + e] = b0[e]; bv[8 * u + 4 + e] = b1[e]; }
+                }
+            }
+            const bool full = m0 + 128 <= p.M && n0 + 256 <= p.N;  // workgroup-uniform
+            if constexpr (EPI == EPI_DGELU) {
+                bf16x8 hs[2][4][2];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        int m = m0 + h2 * 64 + mi * 16 + fr;
+                        m = m < p.M ? m : p.M - 1;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            int n = n0 + wn * 64 + 32 * u + 8 * fq;
+                            n = n < p.N ? n : p.N - 8;
+                            hs[h2][mi][u] = *(const bf16x8*)((const bf16*)p.aux + (long)m * p.ldaux + n);
+                        }
+                    }
+                if (full) {
+                    store_wave_tile<EPI, true, true>(p, acc[0], m0, n0 + wn * 64, fr, fq, bv, hs[0]);
+                    store_wave_tile<EPI, true, true>(p, acc[1], m0 + 64, n0 + wn * 64, fr, fq, bv, hs[1]);
+                } else {
+                    store_wave_tile<EPI, false, true>(p, acc[0], m0, n0 + wn * 64, fr, fq, bv, hs[0]);
+                    store_wave_tile<EPI, false, true>(p, acc[1], m0 + 64, n0 + wn * 64, fr, fq, bv, hs[1]);
+                }
+            } else if (full) {
+                store_wave_tile<EPI, true, true>(p, acc[0], m0, n0 + wn * 64, fr, fq, bv);
+                store_wave_tile<EPI, true, true>(p, acc[1], m0 + 64, n0 + wn * 64, fr, fq, bv);
+            } else {
+                store_wave_tile<EPI, false, true>(p, acc[0], m0, n0 + wn * 64, fr, fq, bv);
+                store_wave_tile<EPI, false, true>(p, acc[1], m0 + 64, n0 + wn * 64, fr, fq, bv);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            kt = 0;
+            tile += G;
+        }
+        // A-lo(T+1), W-lo(T+1) have landed once at most this k-tile's own 12 copy instructions are in flight (after an
+        // epilogue its stores are newer than those copies: the wait then also covers older stores, never fewer copies)
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead copies past the end of the stream
+}
+
+template <int EPI>
+static int launch_nt_p2(const GemmNT& p, hipStream_t s) {
+    static bool reserved = false;
+    if (!reserved) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_p2_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS);
+        if (e != hipSuccess) {
+            mmae_set_error("gemm_nt: cannot reserve %d bytes of LDS: %s", P2_LDS, hipGetErrorString(e));
+            return MMAE_ELAUNCH;
+        }
+        reserved = true;
+    }
+    const int tm = (p.M + 127) / 128, tn = (p.N + 255) / 256;
+    int grid = tm * tn;
+    if (grid > 2 * num_cus()) grid = 2 * num_cus();
+    static int delay_us = -1, khz = 0;  // tuning: MMAE_P2_DELAY_US
+    if (delay_us < 0) {
+        const char* e = getenv("MMAE_P2_DELAY_US");
+        delay_us = e ? atoi(e) : 0;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+            khz = 100000;
+    }
+    const int ticks = grid > num_cus() ? (int)((long long)delay_us * khz / 1000) : 0;  // only when CUs hold two workgroups
+    hipLaunchKernelGGL((gemm_nt_p2_kernel<EPI>), dim3(grid), dim3(256), P2_LDS, s, p, tm, tn, ticks);
+    MMAE_CHECK_LAUNCH("gemm_nt_p2");
+    return MMAE_OK;
+}
+
 static thread_local int g_tn_phase = 0;  // 0 = split GEMM and slab reduction, 1 = GEMM only, 2 = reduction only
 extern "C" void mmae_gemm_tn_set_phase(int phase) { g_tn_phase = phase; }
 static thread_local int g_last_nt = 0, g_last_tn = 0;  // kernel chosen by this thread's last call (same codes as *_set_variant)
@@ -881,6 +1176,20 @@ static int launch_nt(const GemmNT& p, hipStream_t s) {
     const long tiles128 = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     g_nt_full_rows = p.M;
     if (g_nt_variant == 5 && p.K % 128 == 0) { g_last_nt = 5; return launch_nt_pp<EPI>(p, s); }
+    if constexpr (EPI != EPI_TOKENS && EPI != EPI_UNPATCH) {
+        if (g_nt_variant == 7 && p.K % 64 == 0 && p.K >= 128) { g_last_nt = 7; return launch_nt_p2<EPI>(p, s); }
+    }
+    if constexpr (EPI == EPI_GELU || EPI == EPI_DGELU) {
+        // Short reductions under an epilogue that moves a second matrix (the decoders' fc1 + GELU and its backward,
+        // K = 256): the tile time is mostly epilogue, which the two workgroups per CU of the 128x256 kernel overlap
+        // (M = 50176, N = 1024: 78 -> 62 us and 85 -> 65 us).  Its main loop is the slower one, so long reductions stay
+        // with the 256x256 kernel (K = 768: 157 against 174 us).
+        const long tiles_p2 = (long)((p.M + 127) / 128) * ((p.N + 255) / 256);
+        if (g_nt_variant == 0 && p.K % 64 == 0 && p.K >= 128 && p.K <= 256 && p.N >= 512 && tiles_p2 >= 2 * num_cus()) {
+            g_last_nt = 7;
+            return launch_nt_p2<EPI>(p, s);
+        }
+    }
     if (g_nt_variant == 0 && p.K % 128 == 0 && EPI != EPI_TOKENS && EPI != EPI_UNPATCH) {
         const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         const double fill = (double)tiles256 / (pp_plan(p.M, p.N, p.K).rounds * num_cus());

@@ -56,7 +56,8 @@ def _rows2d(t: torch.Tensor, name: str):
 PROFILE = None
 
 
-_NT_KERNELS = {1: "gemm_nt_kernel<%d>", 4: "gemm_nt_persist_kernel<%d, 2, 2>", 5: "gemm_nt_pp_kernel<%d, false>"}
+_NT_KERNELS = {1: "gemm_nt_kernel<%d>", 4: "gemm_nt_persist_kernel<%d, 2, 2>", 5: "gemm_nt_pp_kernel<%d, false>",
+               7: "gemm_nt_p2_kernel<%d>"}
 _TN_KERNELS = {1: "gemm_tn_kernel", 2: "gemm_tn_pp_kernel"}
 
 

@@ -29,14 +29,18 @@ if __name__ == "__main__":
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     shapes_nt = [] if only in ("tn", "attn") else [("qkv", M, 2304, 768, 0), ("proj+res", M, 768, 768, 2), ("fc1+gelu", M, 3072, 768, 1), ("fc2+res", M, 768, 3072, 2),
                  ("dgelu", M, 3072, 768, 3), ("dLN fc1", M, 768, 3072, 0), ("dA qkv", M, 768, 2304, 0), ("dA proj", M, 768, 768, 0), ("dec fc1", 50176, 1024, 256, 1), ("dec qkv", 50176, 768, 256, 0),
-                 ("dec fc2", 50176, 256, 1024, 2), ("pctx", M, 256, 768, 0)]
+                 ("dec fc2", 50176, 256, 1024, 2), ("pctx", M, 256, 768, 0), ("dec dgelu", 50176, 1024, 256, 3), ("dec dLN fc1", 50176, 256, 1024, 0),
+                 ("dec q", 50176, 256, 256, 0), ("dec kv", M, 512, 256, 0), ("dec proj f32", 50176, 256, 256, 4), ("dec dA qkv", 50176, 256, 768, 0),
+                 ("L fc1+gelu", 18496, 4096, 1024, 1), ("L dgelu", 18496, 4096, 1024, 3), ("L qkv", 18496, 3072, 1024, 0)]
+    if only == "dec":
+        shapes_nt = [t for t in shapes_nt if t[0].startswith("dec") or t[0].startswith("L ")]
     for name, m, n, k, epi in shapes_nt:
         a, w = r(m, k), r(n, k)
         bias = torch.randn(n, device="cuda")
         aux = r(m, n, dt=torch.float32) if epi == 2 else (r(m, n) if epi == 3 else None)
         res = []
-        for variant in (1, 4, 6, 5, 0):  # 6 = ping-pong kernel with full tiles only
-            ops._L().mmae_gemm_nt_set_variant(min(variant, 5))
+        for variant in (1, 4, 6, 5, 7, 0):  # 6 = ping-pong kernel with full tiles only, 7 = 128x256 tiles, two workgroups per CU
+            ops._L().mmae_gemm_nt_set_variant(5 if variant == 6 else variant)
             ops._L().mmae_gemm_nt_set_half_tiles(0 if variant == 6 else 1)
             t = timeit(lambda: ops.gemm_nt(epi, a, w, None if epi == 3 else bias, aux=aux))
             res.append(f"{t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
@@ -44,9 +48,9 @@ if __name__ == "__main__":
         # yardstick only (not a product path): the vendor library's plain bf16 product of the same shape, no epilogue
         out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
         t = timeit(lambda: torch.matmul(a, w.t(), out=out))
-        print(f"gemm_nt {name:10s} M={m} N={n} K={k}: t128 {res[0]} | p128 {res[1]} | pp256 full {res[2]} | pp256 {res[3]} | auto {res[4]}"
+        print(f"gemm_nt {name:10s} M={m} N={n} K={k}: t128 {res[0]} | p128 {res[1]} | pp256 full {res[2]} | pp256 {res[3]} | 2wg128x256 {res[4]} | auto {res[5]}"
               f" | vendor plain {t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
-    if len(sys.argv) > 1 and sys.argv[1] == "nt":
+    if len(sys.argv) > 1 and sys.argv[1] in ("nt", "dec"):
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tn":
         pass

@@ -27,9 +27,9 @@ def _randn(*shape, seed=0, dtype=torch.bfloat16, scale=1.0):
 
 
 # ---------------------------------------------------------------------------------------------- GEMM
-@pytest.fixture(params=[1, 4, 5, 6], ids=["tile128", "persist128", "pingpong256", "pingpong256_full_tiles_only"])
+@pytest.fixture(params=[1, 4, 5, 6, 7], ids=["tile128", "persist128", "pingpong256", "pingpong256_full_tiles_only", "two_wg_128x256"])
 def nt_variant(request, ops):
-    ops._L().mmae_gemm_nt_set_variant(min(request.param, 5))
+    ops._L().mmae_gemm_nt_set_variant(5 if request.param == 6 else request.param)
     ops._L().mmae_gemm_nt_set_half_tiles(0 if request.param == 6 else 1)
     yield request.param
     ops._L().mmae_gemm_nt_set_variant(0)
