@@ -116,6 +116,18 @@ class FlatParams:
             self._tr_tiles = tiles
             self.sync_bf16()
 
+    def transpose_table_for(self, start: int, end: int):
+        """(device int32 table, tile count) of the 2-D tensors whose storage lies in flat elements [start, end)."""
+        rows, tiles = [], 0
+        for (name, p), o in zip(self.named, self.offsets):
+            if p.ndim == 2 and start <= o < end:
+                n, k = p.shape
+                rows.append([o, n, k, tiles])
+                tiles += ((n + 63) // 64) * ((k + 63) // 64)
+        if not rows or self.w_bf16 is None:
+            return None, 0
+        return torch.tensor(rows, dtype=torch.int32, device=self.params.device), tiles
+
     def refresh_transposes(self):
         if self._tr_table is not None:
             ops.transpose_multi(self.w_bf16, self.wt_bf16, self._tr_table, self._tr_tiles)
@@ -196,11 +208,24 @@ class GradBuckets:
         self.works = []
         # a one-rank group still runs the collectives when asked to (MMAE_DP_SINGLE_RANK=1: exercises the RCCL path on one GPU)
         self.enabled = self.world > 1 or ((dist.is_initialized() or self.comm is not None) and single)
+        # called as after_bucket(b, start, end, stream) once bucket b's gradients are final (all-reduced when there is an
+        # exchange): `stream` is the stream that work on the bucket must be queued on to be ordered after them
+        self.after_bucket = None
+        self._hooked = False
+        self._comm_pending = False
         if self.enabled:
-            for i, (_, p) in enumerate(flat.named):
-                hook = self._make_hook(i)
-                p.register_post_accumulate_grad_hook(hook)      # gradients delivered by autograd
-                p._mmae_ready = (lambda h=hook, q=p: h(q))       # gradients the kernels wrote in place
+            self.install_hooks()
+
+    def install_hooks(self):
+        """Per-parameter completion signals (idempotent): post-accumulate hooks for gradients delivered by autograd,
+        `_mmae_ready` callbacks for gradients the kernels wrote in place."""
+        if self._hooked:
+            return
+        self._hooked = True
+        for i, (_, p) in enumerate(self.flat.named):
+            hook = self._make_hook(i)
+            p.register_post_accumulate_grad_hook(hook)      # gradients delivered by autograd
+            p._mmae_ready = (lambda h=hook, q=p: h(q))       # gradients the kernels wrote in place
 
     def broadcast_parameters(self, src: int = 0):
         """Every rank takes rank `src`'s parameters and buffers; the bf16 weight copies are rebuilt from them."""
@@ -220,6 +245,8 @@ class GradBuckets:
                 cur.wait_stream(self.comm.stream)
             else:
                 src_global = dist.get_global_rank(self.group, src) if self.group is not None else src
+                if self.flat.params.is_cuda and dist.get_backend(self.group) == "gloo":
+                    torch.cuda.synchronize(self.flat.params.device)  # see _launch: nothing pending under gloo's device copies
                 dist.broadcast(self.flat.params, src=src_global, group=self.group)
                 for t in self.flat.frozen:
                     dist.broadcast(t.data, src=src_global, group=self.group)
@@ -241,14 +268,15 @@ class GradBuckets:
         return hook
 
     def _launch(self, b):
-        """All-reduce bucket b once every kernel that writes it has been enqueued: on the current stream, or on the
-        weight-gradient stream (functional._lin_grads).  The collective is issued from a stream that waits for both."""
+        """Bucket b is complete: every kernel that writes it has been enqueued, on the current stream, a decoder stream or
+        the weight-gradient stream (functional._lin_grads).  All-reduce it (when there is an exchange) from a stream that
+        waits for all of them, then hand it to `after_bucket`."""
         s, e, _ = self.buckets[b]
         buf = self.flat.grads[s:e]
         if buf.is_cuda:  # kernels of several decoder streams may have written into this bucket
             Fn.join_aux_streams(buf.device, reset=False)
         side = Fn.side_stream_pending(buf.device) if buf.is_cuda else None
-        if self.comm is not None:
+        if self.comm is not None and self.enabled:
             # ordered after everything queued so far on the streams that write gradients, and enqueued on the communicator's
             # own stream: the host neither waits nor keeps a handle per collective
             self.comm.stream.wait_stream(torch.cuda.current_stream(buf.device))
@@ -256,12 +284,27 @@ class GradBuckets:
                 self.comm.stream.wait_stream(side)
             self.comm.all_reduce_(buf)
             self._comm_pending = True
+            if self.after_bucket is not None:
+                self.after_bucket(b, s, e, self.comm.stream)
+            return
+        if not self.enabled:  # one rank, nothing to exchange: the bucket only goes to after_bucket
+            if self.after_bucket is not None:
+                if buf.is_cuda and Fn.SIDE_STREAM_DW:
+                    ent = Fn._side(buf.device)
+                    ent[0].wait_stream(torch.cuda.current_stream(buf.device))
+                    self.after_bucket(b, s, e, ent[0])
+                    ent[1] = True
+                else:
+                    self.after_bucket(b, s, e, torch.cuda.current_stream(buf.device) if buf.is_cuda else None)
             return
         # gloo (a rehearsal backend here: several ranks on one GPU) copies device tensors to the host on high-priority streams
-        # of its own that wait on this step's streams by events; such waits can stop the process's queues for good on this
-        # ROCm stack (scripts/prio_inversion.py), the more likely the more work is pending, so each gloo collective on
-        # device tensors is finished before more work is queued.  RCCL (ordinary-priority streams) stays asynchronous.
+        # of its own that wait on this step's streams by events; a high-priority stream waiting for pending work of ordinary
+        # streams can stop the process's queues for good on this ROCm stack (scripts/prio_inversion.py).  So for gloo the
+        # device is drained first (the wait then finds its event complete) and each collective is finished before more work
+        # is queued.  RCCL (ordinary-priority streams) stays asynchronous.
         serial = buf.is_cuda and dist.get_backend(self.group) == "gloo"
+        if serial:
+            torch.cuda.synchronize(buf.device)
         if side is None:
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
@@ -273,9 +316,15 @@ class GradBuckets:
         else:
             self.works.append(work)
 
+    def reset(self):
+        """Forget the completion signals collected so far (nothing may be in flight)."""
+        if not self.works and not self.no_sync:
+            self.pending = [b[2] for b in self.buckets]
+            self.signalled = [False] * len(self.signalled)
+
     def finish(self):
         """Call after backward: launches any bucket whose parameters received no gradient, waits for all."""
-        if not self.enabled or self.no_sync:
+        if not self._hooked or self.no_sync:
             return
         for b, left in enumerate(self.pending):
             if left > 0:
@@ -283,7 +332,7 @@ class GradBuckets:
         for w in self.works:
             w.wait()
         self.works = []
-        if self.comm is not None and getattr(self, "_comm_pending", False):
+        if self.comm is not None and self._comm_pending:
             torch.cuda.current_stream(self.flat.grads.device).wait_stream(self.comm.stream)
             self._comm_pending = False
         self.pending = [b[2] for b in self.buckets]
@@ -353,6 +402,29 @@ class FlatAdamW:
         self.flat.refresh_transposes()
         Fn.bump_weight_epoch()
 
+    def begin_step(self):
+        """Start an optimisation step whose update is applied range by range (step_range) while backward still runs."""
+        if self.param_groups[1]["lr"] != self.param_groups[0]["lr"]:
+            raise ValueError("FlatAdamW applies one learning rate to both parameter groups")
+        self.step_count += 1
+
+    def step_range(self, start: int, end: int, grad_scale: float = 1.0, transpose_table=None):
+        """The update of begin_step()'s step for flat elements [start, end) (a range that does not straddle the decayed /
+        not decayed boundary), on the current stream; `transpose_table` = (int32 table, tiles) of the 2-D weights inside
+        the range refreshes their transposed bf16 copies.  No clipping / skipping: those need the whole gradient first."""
+        nd = self.flat.n_decay
+        if start < nd < end:
+            raise ValueError("step_range: the range straddles the weight-decay boundary")
+        f = self.flat
+        ops.adamw_flat(f.params[start:end], f.grads[start:end], self.exp_avg[start:end], self.exp_avg_sq[start:end],
+                       end - start if start < nd else 0, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                       self.step_count, grad_scale, w_bf16=None if f.w_bf16 is None else f.w_bf16[start:end])
+        if transpose_table is not None and transpose_table[0] is not None:
+            ops.transpose_multi(f.w_bf16, f.wt_bf16, transpose_table[0], transpose_table[1])
+
+    def end_step(self):
+        Fn.bump_weight_epoch()
+
     def grad_norm_sq(self) -> torch.Tensor:
         Fn.join_side_stream(self.flat.grads.device)
         return ops.sumsq(self.flat.grads)
@@ -391,7 +463,8 @@ class PretrainStep:
 
     def __init__(self, model, losses, num_encoded_tokens=98, alphas=1.0, lr=1e-4, weight_decay=0.05, betas=(0.9, 0.95),
                  bucket_mb=64.0, clip_grad=None, skip_grad=None, lr_schedule_values=None, wd_schedule_values=None,
-                 start_step=0, sample_tasks_uniformly=False, fp32_output_adapters=(), standardize_depth=False):
+                 start_step=0, sample_tasks_uniformly=False, fp32_output_adapters=(), standardize_depth=False,
+                 eager_optimizer=None):
         """clip_grad / skip_grad: max_norm / max_skip_norm of the reference's train_one_epoch
         (run_pretraining_multimae.py:512-519).  lr_schedule_values / wd_schedule_values: per-iteration arrays
         (cosine_scheduler) applied before each step as at :424-436; iteration = start_step + calls so far."""
@@ -405,6 +478,27 @@ class PretrainStep:
         self.buckets = GradBuckets(self.flat, bucket_mb=float(os.environ.get("MMAE_BUCKET_MB", bucket_mb)))  # env: tuning
         self.opt = FlatAdamW(self.flat, lr=lr, betas=betas, weight_decay=weight_decay)
         self.world = self.buckets.world
+        # The optimizer is bandwidth-bound work at the end of a step of matrix products.  Without clipping / skipping (which
+        # need the norm of the whole gradient first; the reference's default, pretrain_argparser.py:47-50) a bucket of
+        # parameters can be updated as soon as its gradients are final, beside the rest of backward: on the weight-gradient
+        # stream with one rank, on the communicator's stream behind the bucket's all-reduce with the C ABI's RCCL driver.
+        # (torch.distributed's collectives run on a stream of its own that nothing else can be queued on; waiting for it from
+        # a compute stream would stall that stream, so there the update stays at the end of the step.)
+        if eager_optimizer is None:
+            eager_optimizer = os.environ.get("MMAE_EAGER_OPT", "1") != "0"
+        self.eager = bool(eager_optimizer and clip_grad is None and skip_grad is None and self.flat.params.is_cuda
+                          and (not self.buckets.enabled or self.buckets.comm is not None))
+        if self.eager:
+            self._tr_tables = [self.flat.transpose_table_for(s, e) for s, e, _ in self.buckets.buckets]
+            self.buckets.install_hooks()
+            self.buckets.after_bucket = self._update_bucket
+        self._armed = False
+
+    def _update_bucket(self, b, start, end, stream):
+        if not self._armed:  # a backward pass through the model outside this step (tests, probes): gradients only
+            return
+        with torch.cuda.stream(stream):
+            self.opt.step_range(start, end, grad_scale=1.0 / self.world, transpose_table=self._tr_tables[b])
 
     def __call__(self, batch, mask_randomness=None):
         if self.lr_values is not None:
@@ -413,6 +507,8 @@ class PretrainStep:
             self.opt.weight_decay = float(self.wd_values[self.it])
         self.it += 1
         self.flat.zero_grad()
+        if self.eager:
+            self.opt.begin_step()
         if self.standardize_depth and "depth" in batch:
             batch = dict(batch)
             batch["depth"] = ops.standardize_depth(batch["depth"].contiguous())
@@ -422,12 +518,18 @@ class PretrainStep:
         task_losses = {t: fn(preds[t], batch[tgt], mask=masks.get(tgt)) for t, (fn, tgt) in self.losses.items()}
         loss = sum(task_losses.values())
         Fn.UNIT_LOSS_GRADS = True  # d(loss) / d(task loss) = 1 for every task
+        self.buckets.reset()        # completion signals left by a backward pass outside this step
+        self._armed = True
         try:
             loss.backward()
+            self.buckets.finish()
         finally:
             Fn.UNIT_LOSS_GRADS = False
-        self.buckets.finish()
+            self._armed = False
         Fn.join_side_stream()
         gn2 = self.opt.grad_norm_sq()  # of the summed (not yet averaged) gradients: norm = sqrt(gn2) / world
-        self.opt.step(grad_scale=1.0 / self.world, clip_grad=self.clip_grad, skip_grad=self.skip_grad, grad_sumsq=gn2)
+        if self.eager:
+            self.opt.end_step()  # every bucket was updated as it completed
+        else:
+            self.opt.step(grad_scale=1.0 / self.world, clip_grad=self.clip_grad, skip_grad=self.skip_grad, grad_sumsq=gn2)
         return loss.detach(), task_losses, gn2

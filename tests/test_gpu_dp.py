@@ -191,8 +191,9 @@ def test_two_rank_step_equals_single_rank_on_identical_batches(tmp_path):
     gradient is the single-rank gradient: (g + g) / 2 == g exactly, and two optimizer steps must land on bitwise identical
     parameters.  The ranks run the step with its default streams (weight gradients and decoders on their own).
     (Earlier stalls of this test were gloo's: its device path waits on the step's streams from high-priority streams, which
-    can stop a process's queues on this ROCm stack, see scripts/prio_inversion.py; GradBuckets finishes each gloo
-    collective before queueing more work.  A stall is reported with both ranks' stacks.)"""
+    can stop a process's queues on this ROCm stack while the awaited work is pending, see scripts/prio_inversion.py; both
+    ranks were then found inside the wait for a gloo collective.  GradBuckets drains the device before each gloo collective
+    and finishes it before queueing more work.  A stall is reported with both ranks' stacks.)"""
     out = str(tmp_path / "dp.pt")
     port = 29700 + os.getpid() % 200
     ctx = mp.spawn(_worker, args=(2, port, out), nprocs=2, join=False)

@@ -533,6 +533,37 @@ def test_decoder_streams_do_not_change_the_step():
         assert torch.equal(a, b)
 
 
+def test_bucketwise_optimizer_equals_the_update_at_the_end_of_the_step():
+    """Without clipping the optimizer runs bucket by bucket beside backward (PretrainStep.eager); the element-wise AdamW
+    arithmetic is the same, so three steps must end on bitwise the parameters, moments and bf16 weight copies of the
+    update applied once at the end; with clipping the step falls back to the end-of-step update."""
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    from multimae_amd import functional as Fn
+    from multimae_amd.train import PretrainStep
+    cfg = O.small_cfg()
+    x = {d: t.cuda() for d, t in G.seeded_inputs(cfg, B=4, seed=3).items()}
+    rnd = O.draw_mask_randomness(4, [16, 16], 1.0, torch.Generator().manual_seed(2))
+    res = []
+    for eager in (True, False):
+        model = _build(cfg)
+        model.load_state_dict(G.perturbed_state(cfg, seed=7))
+        model.cuda()
+        step = PretrainStep(model, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05, bucket_mb=0.25, eager_optimizer=eager)
+        assert step.eager == eager and len(step.buckets.buckets) > 3
+        for _ in range(3):
+            loss, _, gn2 = step(x, mask_randomness=rnd)
+        torch.cuda.synchronize()
+        wt = torch.cat([Fn.bf16_weights(q)[1].flatten() for q in model.parameters() if q.requires_grad and q.ndim == 2])
+        res.append((step.flat.params.clone(), step.opt.exp_avg.clone(), step.opt.exp_avg_sq.clone(), step.flat.w_bf16.clone(),
+                    wt, loss.clone(), gn2.clone()))
+        assert step.opt.step_count == 3
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    clipped = PretrainStep(_build(cfg).cuda(), _losses(cfg), num_encoded_tokens=8, clip_grad=1.0)
+    assert not clipped.eager
+
+
 def test_full_batch_step_is_the_mean_of_its_chunks():
     """The bench size (ViT-B/16 RGB-D, 256 images, 98 visible tokens) through a property that does not need the host
     oracle at that size: every sample is processed independently and each loss is a mean over samples, so predictions of
