@@ -36,9 +36,10 @@ CONFIGS = {
                              name="MultiMAE ViT-B/16 RGB+depth+semseg(133 classes, stride 4) 224^2, 98 of 588 tokens visible, "
                                   "4 decoders (rgb, depth, semseg in fp32, norm_rgb)"),
     # multimae/multimae.py:461-478 (ViT-L: 1024 wide, 24 layers, 16 heads) at 384^2; 288 of 1152 tokens visible (the same
-    # quarter as 98 of 392)
+    # quarter as 98 of 392); the reference's per-GPU batch of 256 fits (88 GB of the 288): 64 / 128 / 256 images per step
+    # measured 1,086 / 1,221 / 1,281 images/s (the optimizer's 9 GB pass and the tile rounds amortise)
     "vitl384": dict(model="pretrain_multimae_large", in_domains=("rgb", "depth"), out_domains=("rgb", "depth"), image=384,
-                    k=288, batch=64, gflop=586.3, fp32_out=(), cpu_batch=1,
+                    k=288, batch=256, gflop=586.3, fp32_out=(), cpu_batch=1,
                     name="MultiMAE ViT-L/16 RGB+depth 384^2, 288 visible tokens, 3 decoders (rgb, depth, norm_rgb)"),
 }
 
