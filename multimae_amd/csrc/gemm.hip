@@ -867,7 +867,10 @@ static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
 // matrix).  Here the two workgroups of a CU are independent: one stores while the other multiplies, and the per-SIMD
 // pairing "one wave reads LDS / loads, the other runs its MFMA cluster" comes from the hardware arbiter instead of a
 // barrier protocol.  Price: 48 KB of operands per k-tile for a 128x256 tile against 64 KB for 256x256 (1.5x the L2 -> LDS
-// bytes per FLOP).
+// bytes per FLOP), and a main loop that runs at about 0.7 of the 256x256 kernel's rate (K = 2304, bias-only epilogue: 126 us
+// against 91 us); starting the second workgroup of each CU late, or giving the two unequal issue priorities during their
+// MFMA clusters, changed nothing.  So it pays where the tile time is mostly epilogue: short reductions under the GELU
+// epilogues (K = 256).
 // LDS per workgroup (<= 80 KiB so two fit): a ring of three 8-KiB activation slots (64 rows x 128 B) and a ring of three
 // 16-KiB weight slots (4 waves x 32 rows); k-tile T uses activation slots 2T, 2T+1 (rows 0-63, 64-127) and weight slots
 // 2T, 2T+1 (columns 0-31, 32-63 of every wave's 64) modulo 3.  A k-tile is four phases as in the 256x256 kernel:
@@ -884,15 +887,8 @@ static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
 #define P2_LDS (3 * P2_A_BYTES + 3 * P2_W_BYTES + 4 * 256)  // + per-wave bias slice (64 floats)
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_p2_kernel(GemmNT p, int tiles_m, int tiles_n, int delay_ticks) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_p2_kernel(GemmNT p, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char p2smem[];
-    // The second half of the grid (the workgroups that land beside the first half, one per CU) starts late, so that the two
-    // workgroups of a CU reach their epilogues at different times: started together they would do identical work in
-    // lockstep and store together, which is what this kernel exists to avoid.  Time-bounded wait on the constant-rate clock.
-    if (delay_ticks > 0 && blockIdx.x >= (gridDim.x >> 1)) {
-        const long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < delay_ticks) __builtin_amdgcn_s_sleep(8);
-    }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave;
     const int fr = lane & 15, fq = lane >> 4, swz = fr >> 1;
@@ -1140,16 +1136,7 @@ static int launch_nt_p2(const GemmNT& p, hipStream_t s) {
     const int tm = (p.M + 127) / 128, tn = (p.N + 255) / 256;
     int grid = tm * tn;
     if (grid > 2 * num_cus()) grid = 2 * num_cus();
-    static int delay_us = -1, khz = 0;  // tuning: MMAE_P2_DELAY_US
-    if (delay_us < 0) {
-        const char* e = getenv("MMAE_P2_DELAY_US");
-        delay_us = e ? atoi(e) : 0;
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
-            khz = 100000;
-    }
-    const int ticks = grid > num_cus() ? (int)((long long)delay_us * khz / 1000) : 0;  // only when CUs hold two workgroups
-    hipLaunchKernelGGL((gemm_nt_p2_kernel<EPI>), dim3(grid), dim3(256), P2_LDS, s, p, tm, tn, ticks);
+    hipLaunchKernelGGL((gemm_nt_p2_kernel<EPI>), dim3(grid), dim3(256), P2_LDS, s, p, tm, tn);
     MMAE_CHECK_LAUNCH("gemm_nt_p2");
     return MMAE_OK;
 }
