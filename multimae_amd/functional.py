@@ -546,11 +546,12 @@ class DecoderHeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc, keep32, restore32, meta, pos_table, mask_token, pc_w, pc_b, qn_w, qn_b, cn_w, cn_b, q_w, q_b,
                 kv_w, kv_b, pr_w, pr_b, on_w, on_b, f1w, f1b, f2w, f2b, *task_embs):
-        heads, k, G, T, ntok, q_start = meta
+        heads, k, G, T, ntok, q_start = meta[:6]
         B, seq, D = enc.shape
         Dd = pc_w.shape[0]
         d = Dd // heads
-        enc_b = ops.cast_bf16(enc.contiguous().reshape(B * seq, D))
+        # the bf16 copy of the encoder output, made once by the caller for all decoders (meta[6]) or here
+        enc_b = meta[6] if len(meta) > 6 and meta[6] is not None else ops.cast_bf16(enc.contiguous().reshape(B * seq, D))
         wpc, wpct = bf16_weights(pc_w)
         ctxt = ops.gemm_nt(ops.EPI_BF16, enc_b, wpc, pc_b).reshape(B, seq, Dd)
         emb = ops.build_decoder_emb([None if e is None else e.detach().contiguous() for e in task_embs], pos_table.contiguous(), ntok, Dd)
@@ -576,7 +577,7 @@ class DecoderHeadFn(torch.autograd.Function):
          wqt, wkvt, wprt, wpct, keep32, restore32, meta, dims, (mask_token, task_embs),
          (pc_w, pc_b, qn_w, qn_b, cn_w, cn_b, q_w, q_b, kv_w, kv_b, pr_w, pr_b)) = ctx.saved
         ctx.saved = None
-        heads, k, G, T, ntok, q_start = meta
+        heads, k, G, T, ntok, q_start = meta[:6]
         B, seq, D, Dd = dims
         d = Dd // heads
         dx, g_mlp = _mlp_bwd(g.contiguous().reshape(B * ntok, Dd), s_mlp)

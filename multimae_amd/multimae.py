@@ -218,6 +218,11 @@ class MultiMAE(nn.Module):
         def decode(d):
             return self.output_adapters[d](encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep,
                                            ids_restore=ids_restore, fp32_output=d in fp32_output_adapters)
+        if encoder_tokens.is_cuda and len(self.output_adapters) > 1:
+            # every decoder projects the same encoder output: one bf16 copy for all of them, made before they are dealt over
+            # the streams (DecoderHeadFn would otherwise cast it once per decoder)
+            Bq, Nq, Dq = encoder_tokens.shape
+            input_info["_enc_bf16"] = ops.cast_bf16(encoder_tokens.detach().contiguous().reshape(Bq * Nq, Dq))
         lanes = Fn.decoder_lanes(encoder_tokens.device, len(self.output_adapters)) if encoder_tokens.is_cuda else None
         if lanes is not None:
             # the decoders are independent until the losses: dealt over the main stream and the decoder streams; same
@@ -227,6 +232,8 @@ class MultiMAE(nn.Module):
             for st in lanes:  # before any decoder is queued: a later wait would put that lane behind the decoders on main
                 if st != main:
                     st.wait_stream(main)
+                    if "_enc_bf16" in input_info:
+                        input_info["_enc_bf16"].record_stream(st)  # allocated on the main stream, read on this one
             for i, d in enumerate(self.output_adapters):
                 st = where[d] = lanes[i % len(lanes)]
                 with torch.cuda.stream(st):

@@ -103,7 +103,10 @@ class SpatialOutputAdapter(nn.Module):
             keep32, restore32 = ids_keep.to(torch.int32).contiguous(), ids_restore.to(torch.int32).contiguous()
         embs = [self.task_embeddings[t] if (self.task_embeddings is not None and t in self.task_embeddings) else None for t in tasks]
         d, m = self.decoder, self.mlp
-        meta = (self.num_heads, k, G, len(tasks), ntok, q_start)
+        enc_b = input_info.get("_enc_bf16")  # made once for all decoders by MultiMAE.forward
+        if enc_b is not None and (enc_b.shape[0] != encoder_tokens.shape[0] * encoder_tokens.shape[1] or enc_b.device != encoder_tokens.device):
+            enc_b = None
+        meta = (self.num_heads, k, G, len(tasks), ntok, q_start, enc_b)
         x = Fn.DecoderHeadFn.apply(
             encoder_tokens, keep32, restore32, meta, self._pos_table(nh, nw), self.mask_token,
             self.proj_context.weight, self.proj_context.bias, self.query_norm.weight, self.query_norm.bias,
