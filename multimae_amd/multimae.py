@@ -21,6 +21,9 @@ from .output_adapters import SpatialOutputAdapter
 
 __all__ = ["MultiMAE", "pretrain_multimae_base", "pretrain_multimae_large", "create_model"]
 
+import os as _os
+_SHARED_ENC_CAST = _os.environ.get("MMAE_SHARED_ENC_CAST", "1") != "0"  # tuning switch
+
 
 class MultiMAE(nn.Module):
     """Multi-modal masked autoencoder: per-domain patch adapters, Dirichlet-budgeted random masking, a ViT encoder
@@ -218,7 +221,7 @@ class MultiMAE(nn.Module):
         def decode(d):
             return self.output_adapters[d](encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep,
                                            ids_restore=ids_restore, fp32_output=d in fp32_output_adapters)
-        if encoder_tokens.is_cuda and len(self.output_adapters) > 1:
+        if encoder_tokens.is_cuda and len(self.output_adapters) > 1 and _SHARED_ENC_CAST:
             # every decoder projects the same encoder output: one bf16 copy for all of them, made before they are dealt over
             # the streams (DecoderHeadFn would otherwise cast it once per decoder)
             Bq, Nq, Dq = encoder_tokens.shape

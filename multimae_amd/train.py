@@ -464,7 +464,7 @@ class PretrainStep:
     def __init__(self, model, losses, num_encoded_tokens=98, alphas=1.0, lr=1e-4, weight_decay=0.05, betas=(0.9, 0.95),
                  bucket_mb=64.0, clip_grad=None, skip_grad=None, lr_schedule_values=None, wd_schedule_values=None,
                  start_step=0, sample_tasks_uniformly=False, fp32_output_adapters=(), standardize_depth=False,
-                 eager_optimizer=None):
+                 eager_optimizer=None, max_steps_in_flight=None):
         """clip_grad / skip_grad: max_norm / max_skip_norm of the reference's train_one_epoch
         (run_pretraining_multimae.py:512-519).  lr_schedule_values / wd_schedule_values: per-iteration arrays
         (cosine_scheduler) applied before each step as at :424-436; iteration = start_step + calls so far."""
@@ -493,6 +493,16 @@ class PretrainStep:
             self.buckets.install_hooks()
             self.buckets.after_bucket = self._update_bucket
         self._armed = False
+        # The host enqueues a step several times faster than the device runs it and never has to wait for it, so without a
+        # bound it runs many steps ahead.  Memory then grows with the distance: buffers that were used on a second stream are
+        # only reusable once that stream has passed them (record_stream), and every step in flight holds its own set (ViT-L/16
+        # 384^2 at 256 images: step times of 0.3-0.8 s instead of 0.2 s from allocator traffic, then a queue abort with
+        # HSA_STATUS_ERROR_OUT_OF_RESOURCES).  Before enqueueing step i the host therefore waits for step
+        # i - max_steps_in_flight to have finished: the queues stay at least one whole step deep, the device never idles.
+        if max_steps_in_flight is None:
+            max_steps_in_flight = int(os.environ.get("MMAE_MAX_STEPS_IN_FLIGHT", "2"))
+        self.max_in_flight = max_steps_in_flight if self.flat.params.is_cuda else 0
+        self._step_events = []
 
     def _update_bucket(self, b, start, end, stream):
         if not self._armed:  # a backward pass through the model outside this step (tests, probes): gradients only
@@ -506,6 +516,11 @@ class PretrainStep:
         if self.wd_values is not None and self.opt.weight_decay > 0:
             self.opt.weight_decay = float(self.wd_values[self.it])
         self.it += 1
+        if self.max_in_flight > 0:
+            while len(self._step_events) >= self.max_in_flight:
+                ev = self._step_events.pop(0)
+                if not ev.query():
+                    ev.synchronize()
         self.flat.zero_grad()
         if self.eager:
             self.opt.begin_step()
@@ -532,4 +547,8 @@ class PretrainStep:
             self.opt.end_step()  # every bucket was updated as it completed
         else:
             self.opt.step(grad_scale=1.0 / self.world, clip_grad=self.clip_grad, skip_grad=self.skip_grad, grad_sumsq=gn2)
+        if self.max_in_flight > 0:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._step_events.append(ev)
         return loss.detach(), task_losses, gn2

@@ -8,6 +8,9 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
 echo "bench" > $OUT/progress.txt
 timeout -k 10 400 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+echo "bench, other configurations" >> $OUT/progress.txt
+timeout -k 10 400 python3 $R/bench.py --config vitb_rgbd_semseg > $OUT/bench_vitb_rgbd_semseg.json 2> $OUT/bench_semseg.err
+timeout -k 10 600 python3 $R/bench.py --config vitl384 --steps 10 --warmup 3 > $OUT/bench_vitl384.json 2> $OUT/bench_vitl384.err
 echo "serial trace" >> $OUT/progress.txt
 MMAE_SIDE_STREAM=0 MMAE_DEC_STREAMS=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial -o s -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/serial.log 2>&1
 echo "overlapped trace" >> $OUT/progress.txt
