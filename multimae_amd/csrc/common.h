@@ -86,32 +86,43 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * 0.39894228040143267794f * e;
 }
 
-// GELU and its derivative for eight values at once on the packed fp32 ALU, without transcendentals.  Both
-// Phi(x) - 1/2 and gelu'(x) - 1/2 are odd functions: x * P(u) with u = x^2 scaled to [-1, 1] (least-squares fits on
-// Chebyshev nodes), saturating to +-1/2 beyond |x| = 4 (4.5).  Absolute error <= 3.2e-5 (7e-5), below the bf16 rounding of
-// the stored result for every value that matters; a GEMM epilogue with the rcp/exp2 form spent a quarter of the tile time here.
+// GELU and its derivative on the packed fp32 ALU, without transcendentals.  Both Phi(x) - 1/2 and gelu'(x) - 1/2 are odd
+// functions: x * P(u) with u = x^2 scaled to [-1, 1] (least squares on Chebyshev nodes, scripts/fit_gelu_poly.py), fitted
+// under the condition that the value at the end of the range is exactly 1/2: the argument is clamped to the range and the
+// saturated branches (+-1/2 beyond |x| = 4, 4.5) need no select.  Absolute error <= 3.4e-5 (6.9e-5), below the bf16
+// rounding of the stored result for every value that matters; a GEMM epilogue with the rcp/exp2 form spent a quarter of the
+// tile time here.  NP pairs are evaluated side by side, coefficient by coefficient: a dependent chain of packed FMAs costs
+// a wait state per link, independent chains fill them.
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-__device__ __forceinline__ f32x2 odd_poly2(f32x2 x, const float* c, int n, float inv_half_range, float xmax) {
-    const f32x2 u = x * x * inv_half_range - 1.0f;
-    f32x2 acc = {c[n - 1], c[n - 1]};
+template <int NP, int NC>
+__device__ __forceinline__ void odd_poly2(const f32x2 (&x)[NP], f32x2 (&r)[NP], const float (&c)[NC], float inv_half_range, float xmax) {
+    f32x2 xc[NP], u[NP];
 #pragma unroll
-    for (int k = n - 2; k >= 0; --k) acc = acc * u + c[k];
-    f32x2 r = x * acc;
+    for (int i = 0; i < NP; ++i) {
+        xc[i] = (f32x2){__builtin_amdgcn_fmed3f(x[i][0], -xmax, xmax), __builtin_amdgcn_fmed3f(x[i][1], -xmax, xmax)};
+        u[i] = xc[i] * xc[i] * inv_half_range - 1.0f;
+        r[i] = (f32x2){c[NC - 1], c[NC - 1]};
+    }
 #pragma unroll
-    for (int e = 0; e < 2; ++e) r[e] = fabsf(x[e]) >= xmax ? copysignf(0.5f, x[e]) : r[e];
-    return r;
+    for (int k = NC - 2; k >= 0; --k)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) r[i] = r[i] * u[i] + c[k];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) r[i] = xc[i] * r[i];
 }
-__device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {  // x * Phi(x)
-    const float c[9] = {0.1759490966796875f, -0.08430877327919006f, 0.05595685914158821f, -0.03706042096018791f,
-                        0.022424334660172462f, -0.011718817986547947f, 0.006272502709180117f, -0.0038783808704465628f,
-                        0.0013566274428740144f};
-    return x * (odd_poly2(x, c, 9, 2.0f / 16.0f, 4.0f) + 0.5f);
+template <int NP>
+__device__ __forceinline__ void gelu_poly2(const f32x2 (&x)[NP], f32x2 (&g)[NP]) {  // x * Phi(x)
+    const float c[8] = {0.1759425550699234f, -0.084359310567379f, 0.05620153620839119f, -0.0365694984793663f, 0.021034933626651764f, -0.012868070974946022f, 0.008746585808694363f, -0.0031287299934774637f};
+    odd_poly2<NP, 8>(x, g, c, 2.0f / 16.0f, 4.0f);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) g[i] = x[i] * (g[i] + 0.5f);
 }
-__device__ __forceinline__ f32x2 gelu_grad_poly2(f32x2 x) {  // Phi(x) + x * phi(x)
-    const float c[11] = {0.15943185985088348f, -0.09001392871141434f, 0.08697269856929779f, -0.09390359371900558f,
-                         0.09800127893686295f, -0.09394010901451111f, 0.06953548640012741f, -0.03601986914873123f,
-                         0.02863761968910694f, -0.029474526643753052f, 0.011901799589395523f};
-    return odd_poly2(x, c, 11, 2.0f / 20.25f, 4.5f) + 0.5f;
+template <int NP>
+__device__ __forceinline__ void gelu_grad_poly2(const f32x2 (&x)[NP], f32x2 (&d)[NP]) {  // Phi(x) + x * phi(x)
+    const float c[10] = {0.15944573283195496f, -0.08991280198097229f, 0.0861779972910881f, -0.09547753632068634f, 0.10513326525688171f, -0.08748847991228104f, 0.04747903347015381f, -0.04563887044787407f, 0.05615197867155075f, -0.024759210646152496f};
+    odd_poly2<NP, 10>(x, d, c, 2.0f / 20.25f, 4.5f);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) d[i] = d[i] + 0.5f;
 }
 
 // async 16-byte global -> LDS copy; `lds_wave_base` must be wave-uniform, lane i lands at +16*i

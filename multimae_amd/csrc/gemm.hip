@@ -19,7 +19,7 @@ __device__ uint4 g_zero_page[4];  // 64 bytes of zeros: DMA source for out-of-ra
 
 enum {
     EPI_BF16 = 0,      // out bf16 = acc (+bias)
-    EPI_GELU = 1,      // out bf16 = h = acc+bias ; out2 bf16 = gelu(h)
+    EPI_GELU = 1,      // out bf16 = h = acc+bias ; out2 bf16 = gelu(acc+bias) (from the fp32 value, before h is rounded)
     EPI_RESID = 2,     // out f32 = aux_f32 + acc + bias
     EPI_DGELU = 3,     // out bf16 = acc * gelu'(aux_bf16)
     EPI_F32 = 4,       // out f32 = acc (+bias)
@@ -132,11 +132,9 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = acc[2 * u][mi][e]; v[4 + e] = acc[2 * u + 1][mi][e]; }
             if (USES_BIAS) {
-                if (BREG) {
-                    if (p.bias) {
+                if (BREG) {  // zeros when there is no bias
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += bias_regs[8 * u + e];
-                    }
+                    for (int e = 0; e < 8; ++e) v[e] += bias_regs[8 * u + e];
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += bl[8 * u + e];
@@ -149,11 +147,14 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
                 *(bf16x8*)((bf16*)p.out + orow * p.ldo + n) = o;
             } else if (EPI == EPI_GELU) {
                 bf16x8 h, g;
+                f32x2 xv[4], gv[4];
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    h[e] = (bf16)v[e]; h[e + 1] = (bf16)v[e + 1];
-                    const f32x2 a = gelu_poly2((f32x2){(float)h[e], (float)h[e + 1]});
-                    g[e] = (bf16)a[0]; g[e + 1] = (bf16)a[1];
+                for (int e = 0; e < 4; ++e) xv[e] = (f32x2){v[2 * e], v[2 * e + 1]};
+                gelu_poly2<4>(xv, gv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[2 * e] = (bf16)v[2 * e]; h[2 * e + 1] = (bf16)v[2 * e + 1];
+                    g[2 * e] = (bf16)gv[e][0]; g[2 * e + 1] = (bf16)gv[e][1];
                 }
                 *(bf16x8*)((bf16*)p.out + orow * p.ldo + n) = h;
                 *(bf16x8*)((bf16*)p.out2 + orow * p.ldo + n) = g;
@@ -165,11 +166,12 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
             } else if (EPI == EPI_DGELU) {
                 const bf16x8 h = h_regs ? h_regs[mi][u] : hsv[EPI == EPI_DGELU ? mi % MB : 0][u];
                 bf16x8 o;
+                f32x2 xv[4], dv[4];
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    const f32x2 d = gelu_grad_poly2((f32x2){(float)h[e], (float)h[e + 1]});
-                    o[e] = (bf16)(v[e] * d[0]); o[e + 1] = (bf16)(v[e + 1] * d[1]);
-                }
+                for (int e = 0; e < 4; ++e) xv[e] = (f32x2){(float)h[2 * e], (float)h[2 * e + 1]};
+                gelu_grad_poly2<4>(xv, dv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[2 * e] = (bf16)(v[2 * e] * dv[e][0]); o[2 * e + 1] = (bf16)(v[2 * e + 1] * dv[e][1]); }
                 *(bf16x8*)((bf16*)p.out + orow * p.ldo + n) = o;
             } else if (EPI == EPI_F32) {
                 float* op = (float*)p.out + orow * p.ldo + n;
@@ -204,6 +206,130 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
                     }
                 }
             }
+        }
+    }
+}
+
+// The same 64x64 block, full tiles only, with every global access covering whole 128-byte rows.
+// In the accumulator layout neighbouring lanes hold neighbouring ROWS, so a 16-byte store (or load) per lane touches 64
+// separate segments and a CU moves about 33 GB/s however few CUs are active; with eight neighbouring lanes on one 128-byte
+// row the same instruction runs at about 130 GB/s per CU.  The block therefore goes through a 2-KiB piece of LDS owned by
+// the wave, 16 rows x 128 bytes at a time: written in the accumulator layout (lane (fr, fq) -> row fr, 16-byte chunks
+// {fq, 4 + fq} for bf16, {2fq, 2fq + 1} for fp32), read back with lane l on row (l >> 3) + 8j, chunk l & 7.  Chunk c of
+// row r sits at c ^ ((r >> 1) & 7): both directions are free of bank conflicts.  DS operations of one wave execute in
+// order, so no barrier is involved.
+//   bf16 outputs: one piece per fragment row mi (64 columns x 2 bytes); fp32 outputs: one piece per (mi, u) (32 columns)
+//   EPI_DGELU: h_rows[mi][j] holds the saved pre-activations in the ROW layout (fetched by the caller ahead of the stores);
+//              they pass through the same piece to reach the accumulator layout
+//   EPI_RESID: the residual is fetched and added in the row layout, RES_AHEAD pieces ahead of the stores
+template <int EPI>
+__device__ __forceinline__ void store_wave_tile_rows(const GemmNT& p, const f32x4 (&acc)[4][4], int mw, int nw, int lane,
+                                                     char* stage, const float* bias_regs, const bf16x8 (*h_rows)[2] = nullptr) {
+    static_assert(EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_RESID || EPI == EPI_DGELU || EPI == EPI_F32, "row-major epilogues");
+    const int fr = lane & 15, fq = lane >> 4;
+    const int rr = lane >> 3, cc = lane & 7;
+    char* const wrow = stage + fr * 128;
+    const int wsw = (fr >> 1) & 7;
+    // read side: rows rr and rr + 8 -> swizzles (rr >> 1) & 3 and 4 + ((rr >> 1) & 3)
+    char* const rd0 = stage + rr * 128 + ((cc ^ ((rr >> 1) & 7)) << 4);
+    char* const rd1 = stage + (rr + 8) * 128 + ((cc ^ (((rr + 8) >> 1) & 7)) << 4);
+    constexpr bool F32OUT = EPI == EPI_RESID || EPI == EPI_F32;
+    if constexpr (!F32OUT) {
+        bf16* const o0 = (bf16*)p.out + (long)(mw + rr) * p.ldo + nw + 8 * cc;
+        bf16* const o20 = EPI == EPI_GELU ? (bf16*)p.out2 + (long)(mw + rr) * p.ldo + nw + 8 * cc : nullptr;
+        char* const w0 = wrow + ((fq ^ wsw) << 4);
+        char* const w1 = wrow + (((4 + fq) ^ wsw) << 4);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            bf16x8 hacc[2];
+            if constexpr (EPI == EPI_DGELU) {
+                *(bf16x8*)rd0 = h_rows[mi][0];
+                *(bf16x8*)rd1 = h_rows[mi][1];
+                hacc[0] = *(const bf16x8*)w0;
+                hacc[1] = *(const bf16x8*)w1;
+            }
+            bf16x8 o[2], g[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = acc[2 * u][mi][e]; v[4 + e] = acc[2 * u + 1][mi][e]; }
+                if constexpr (EPI != EPI_DGELU) {  // zeros when there is no bias
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bias_regs[8 * u + e];
+                }
+                if constexpr (EPI == EPI_BF16) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[u][e] = (bf16)v[e];
+                } else if constexpr (EPI == EPI_GELU) {
+                    f32x2 xv[4], gv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[e] = (f32x2){v[2 * e], v[2 * e + 1]};
+                    gelu_poly2<4>(xv, gv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[u][2 * e] = (bf16)v[2 * e]; o[u][2 * e + 1] = (bf16)v[2 * e + 1];
+                        g[u][2 * e] = (bf16)gv[e][0]; g[u][2 * e + 1] = (bf16)gv[e][1];
+                    }
+                } else {  // EPI_DGELU
+                    f32x2 xv[4], dv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[e] = (f32x2){(float)hacc[u][2 * e], (float)hacc[u][2 * e + 1]};
+                    gelu_grad_poly2<4>(xv, dv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[u][2 * e] = (bf16)(v[2 * e] * dv[e][0]); o[u][2 * e + 1] = (bf16)(v[2 * e + 1] * dv[e][1]);
+                    }
+                }
+            }
+            *(bf16x8*)w0 = o[0];
+            *(bf16x8*)w1 = o[1];
+            const bf16x8 r0 = *(const bf16x8*)rd0, r1 = *(const bf16x8*)rd1;
+            *(bf16x8*)(o0 + (long)(mi * 16) * p.ldo) = r0;
+            *(bf16x8*)(o0 + (long)(mi * 16 + 8) * p.ldo) = r1;
+            if constexpr (EPI == EPI_GELU) {
+                *(bf16x8*)w0 = g[0];
+                *(bf16x8*)w1 = g[1];
+                const bf16x8 g0 = *(const bf16x8*)rd0, g1 = *(const bf16x8*)rd1;
+                *(bf16x8*)(o20 + (long)(mi * 16) * p.ldo) = g0;
+                *(bf16x8*)(o20 + (long)(mi * 16 + 8) * p.ldo) = g1;
+            }
+        }
+    } else {
+        // pieces in the order (mi, u): 16 rows x 32 fp32 columns
+        constexpr int RES_AHEAD = 3;
+        float* const o0 = (float*)p.out + (long)(mw + rr) * p.ldo + nw + 4 * cc;
+        const float* const a0 = EPI == EPI_RESID ? (const float*)p.aux + (long)(mw + rr) * p.ldaux + nw + 4 * cc : nullptr;
+        char* const w0 = wrow + (((2 * fq) ^ wsw) << 4);
+        char* const w1 = wrow + (((2 * fq + 1) ^ wsw) << 4);
+        f32x4 res[RES_AHEAD + 1][2];
+        auto load_res = [&](int piece) {
+            const int mi = piece >> 1, u = piece & 1;
+            res[piece % (RES_AHEAD + 1)][0] = *(const f32x4*)(a0 + (long)(mi * 16) * p.ldaux + 32 * u);
+            res[piece % (RES_AHEAD + 1)][1] = *(const f32x4*)(a0 + (long)(mi * 16 + 8) * p.ldaux + 32 * u);
+        };
+        if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+            for (int q = 0; q < RES_AHEAD; ++q) load_res(q);
+        }
+#pragma unroll
+        for (int piece = 0; piece < 8; ++piece) {
+            const int mi = piece >> 1, u = piece & 1;
+            if constexpr (EPI == EPI_RESID) {
+                if (piece + RES_AHEAD < 8) load_res(piece + RES_AHEAD);
+            }
+            f32x4 v0 = acc[2 * u][mi], v1 = acc[2 * u + 1][mi];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] += bias_regs[8 * u + e]; v1[e] += bias_regs[8 * u + 4 + e]; }
+            *(f32x4*)w0 = v0;
+            *(f32x4*)w1 = v1;
+            f32x4 r0 = *(const f32x4*)rd0, r1 = *(const f32x4*)rd1;
+            if constexpr (EPI == EPI_RESID) {
+                r0 += res[piece % (RES_AHEAD + 1)][0];
+                r1 += res[piece % (RES_AHEAD + 1)][1];
+            }
+            *(f32x4*)(o0 + (long)(mi * 16) * p.ldo + 32 * u) = r0;
+            *(f32x4*)(o0 + (long)(mi * 16 + 8) * p.ldo + 32 * u) = r1;
         }
     }
 }
@@ -462,6 +588,10 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 ? 2 : 2)) void gemm_nt_persist_k
 // Slot images: 128 rows x 128 B; slot 0 / 3 hold activation rows {wm*128 + (0|64) + 0..63}, slot 1 / 2 weight rows
 // {wn*64 + (0|32) + 0..31}; 16-byte chunk c of row r sits at c ^ swz(r) (same two swizzles as the 128x128 kernel).
 // Requires K % 128 == 0 (k-tiles come in pairs, one per LDS buffer).
+// Tile end: per-tile timestamps (the MMAE_PP_TRACE build, scripts/pp_trace.py) show the time between main loops to be the
+// VALU work of the epilogue, not the stores: the counted wait after it costs 0.04 us, and spreading the start of the
+// workgroups over a whole tile time (so that CUs do not store together) changes no per-tile figure.  What mattered: the two
+// groups' epilogues running side by side (see the barrier at the tile end), and the instruction count per value.
 // HALF: 128x256 tiles for the tail of a problem.  A workgroup owns a CU, so a last round with few tiles leaves most CUs
 // idle for a whole tile time; the launcher may instead give the last row panels to a second launch of this instance, in
 // which slot 0 holds 128 contiguous rows (64 per wave group, one 64x64 block per wave), slot 3 and the second
@@ -470,8 +600,20 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 ? 2 : 2)) void gemm_nt_persist_k
 // ------------------------------------------------------------------------------------------
 #define PP_H_BYTES 16384
 #define PP_KT_BYTES (4 * PP_H_BYTES)
-#define PP_LDS (2 * PP_KT_BYTES + 8 * 256)  // + per-wave bias slice (64 floats)
+#define PP_LDS (2 * PP_KT_BYTES + 8 * 256 + 8 * 2048)  // + per-wave bias slice (64 floats) + per-wave epilogue piece
 
+#ifdef MMAE_PP_TRACE
+// timing build only: per workgroup and wave group, eight 100 MHz timestamps per tile: 0 end of main loop, 1 stores issued,
+// then in the next tile's first k-tile: 2 past the first barrier, 3 before / 4 after the counted wait of phase 3, 5 k-tile done;
+// 7 (first record only) start of the main loop
+__device__ unsigned long long g_pp_trace[256 * 2 * 128];
+extern "C" int mmae_debug_pp_trace(void* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pp_trace), sizeof(g_pp_trace)) == hipSuccess ? 0 : 1;
+}
+#define PP_TRACE(slot) do { if (!HALF && lane == 0 && wn == 0 && me < 256 && trace_tile < 16) g_pp_trace[(me * 2 + wm) * 128 + trace_tile * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define PP_TRACE(slot) do {} while (0)
+#endif
 template <int EPI, bool HALF>
 __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char ppsmem[];
@@ -485,6 +627,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
     const int my_tiles = (ntiles - 1 - me) / G + 1;
     const int total_kt = my_tiles * nk;
     float* bias_lds = (float*)(ppsmem + 2 * PP_KT_BYTES) + wave * 64;
+    if (!p.bias) bias_lds[lane] = 0.f;
 
     auto tile_origin = [&](int t, int& m0, int& n0) {
         if (HALF) {  // column tiles fastest: neighbouring workgroups share the 128 activation rows
@@ -608,6 +751,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
     if (wm == 1) __builtin_amdgcn_s_barrier();  // second wave group runs one barrier behind
 
     int tile = me, kt = 0;
+#ifdef MMAE_PP_TRACE
+    int trace_tile = 0;
+    PP_TRACE(7);
+    ++trace_tile;
+#endif
     for (int T = 0; T < total_kt; T += 2) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -661,6 +809,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
             stage_slot(S3{});
             asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // the slot-0 reads are done before the barrier: slot 0 is refilled next phase
             __builtin_amdgcn_s_barrier();
+#ifdef MMAE_PP_TRACE
+            if (kt == 0 && b == 0) PP_TRACE(-6);
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             mfma_quad(acc[0], 0, wlo);
@@ -683,51 +834,71 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
             __builtin_amdgcn_s_barrier();
             // ---- phase 3 ----
             stage_slot(S2{});
+#ifdef MMAE_PP_TRACE
+            if (kt == 0 && b == 0) PP_TRACE(-5);
+#endif
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // all but the newest three half-tiles: the next k-tile has landed
+#ifdef MMAE_PP_TRACE
+            if (kt == 0 && b == 0) PP_TRACE(-4);
+#endif
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             mfma_quad(acc[HALF ? 0 : 1], 0, wlo);
             __builtin_amdgcn_s_barrier();
+#ifdef MMAE_PP_TRACE
+            if (kt == 0 && b == 0) PP_TRACE(-3);  // slot 5 of the previous tile's record
+#endif
         }
         kt += 2;
         if (kt == nk) {
+            // The second wave group is one barrier behind: its last MFMA cluster of the tile sits between two barriers that
+            // this group would only reach after its epilogue (the first of the next tile), and this group would then wait
+            // in the next tile's first phase for the second group's epilogue: two epilogues per tile, one after the other.
+            // One more barrier on each side (here, and after the second group's epilogue) releases the second group at once,
+            // so the two epilogues run side by side, and leaves the groups one barrier apart again for the next tile.
+            if (wm == 0) __builtin_amdgcn_s_barrier();
+            PP_TRACE(0);
             int m0, n0;
             tile_origin(tile, m0, n0);
-            float bv[16];
-            if (p.bias) {
+            float bv[16];  // the wave's bias slice (zeros without a bias: written once at the start)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const f32x4 b0 = *(const f32x4*)(bias_lds + 32 * u + 8 * fq), b1 = *(const f32x4*)(bias_lds + 32 * u + 8 * fq + 4);
+            for (int u = 0; u < 2; ++u) {
+                const f32x4 b0 = *(const f32x4*)(bias_lds + 32 * u + 8 * fq), b1 = *(const f32x4*)(bias_lds + 32 * u + 8 * fq + 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { bv[8 * u + e] = b0[e]; bv[8 * u + 4 + e] = b1[e]; }
-                }
+                for (int e = 0; e < 4; ++e) { bv[8 * u + e] = b0[e]; bv[8 * u + 4 + e] = b1[e]; }
             }
             const bool full = m0 + (HALF ? 128 : 256) <= p.M && n0 + 256 <= p.N;  // workgroup-uniform
             const int rb = m0 + wm * (HALF ? 64 : 128);                            // first row of this wave's block
             constexpr int NH2 = HALF ? 1 : 2;
-            if constexpr (EPI == EPI_DGELU) {
-                // the saved pre-activations of the whole 128x64 block first: one wait for them (and for the loads still in
-                // flight ahead of them) instead of one per half
-                bf16x8 hs[NH2][4][2];
+#ifdef MMAE_PP_ACC_EPILOGUE  // timing builds: stores straight from the accumulator layout
+            constexpr bool ROWS = false;
+#else
+            constexpr bool ROWS = EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_RESID || EPI == EPI_DGELU || EPI == EPI_F32;
+#endif
+            if constexpr (ROWS) {
+                if (full) {  // whole rows per access, through the wave's LDS piece
+                    char* stage = ppsmem + 2 * PP_KT_BYTES + 8 * 256 + wave * 2048;
+                    if constexpr (EPI == EPI_DGELU) {
+                        // the saved pre-activations of the whole 128x64 block first, in the row layout: one wait for them
+                        // (and for the loads still in flight ahead of them) instead of one per piece
+                        bf16x8 hs[NH2][4][2];
+                        const bf16* hp = (const bf16*)p.aux + (long)(rb + (lane >> 3)) * p.ldaux + n0 + wn * 64 + 8 * (lane & 7);
 #pragma unroll
-                for (int h2 = 0; h2 < NH2; ++h2)
+                        for (int h2 = 0; h2 < NH2; ++h2)
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) {
-                        int m = rb + h2 * 64 + mi * 16 + fr;
-                        m = m < p.M ? m : p.M - 1;
+                            for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            int n = n0 + wn * 64 + 32 * u + 8 * fq;
-                            n = n < p.N ? n : p.N - 8;
-                            hs[h2][mi][u] = *(const bf16x8*)((const bf16*)p.aux + (long)m * p.ldaux + n);
-                        }
+                                for (int j = 0; j < 2; ++j)
+                                    hs[h2][mi][j] = *(const bf16x8*)(hp + (long)(h2 * 64 + mi * 16 + 8 * j) * p.ldaux);
+                        store_wave_tile_rows<EPI>(p, acc[0], rb, n0 + wn * 64, lane, stage, bv, hs[0]);
+                        if (!HALF) store_wave_tile_rows<EPI>(p, acc[NH2 - 1], rb + 64, n0 + wn * 64, lane, stage, bv, hs[NH2 - 1]);
+                    } else {
+                        store_wave_tile_rows<EPI>(p, acc[0], rb, n0 + wn * 64, lane, stage, bv);
+                        if (!HALF) store_wave_tile_rows<EPI>(p, acc[NH2 - 1], rb + 64, n0 + wn * 64, lane, stage, bv);
                     }
-                if (full) {
-                    store_wave_tile<EPI, true, true>(p, acc[0], rb, n0 + wn * 64, fr, fq, bv, hs[0]);
-                    if (!HALF) store_wave_tile<EPI, true, true>(p, acc[NH2 - 1], rb + 64, n0 + wn * 64, fr, fq, bv, hs[NH2 - 1]);
                 } else {
-                    store_wave_tile<EPI, false, true>(p, acc[0], rb, n0 + wn * 64, fr, fq, bv, hs[0]);
-                    if (!HALF) store_wave_tile<EPI, false, true>(p, acc[NH2 - 1], rb + 64, n0 + wn * 64, fr, fq, bv, hs[NH2 - 1]);
+                    store_wave_tile<EPI, false, !(EPI == EPI_DGELU)>(p, acc[0], rb, n0 + wn * 64, fr, fq, bv);
+                    if (!HALF) store_wave_tile<EPI, false, !(EPI == EPI_DGELU)>(p, acc[NH2 - 1], rb + 64, n0 + wn * 64, fr, fq, bv);
                 }
             } else if (full) {
                 store_wave_tile<EPI, true, true, HALF>(p, acc[0], rb, n0 + wn * 64, fr, fq, bv);
@@ -744,6 +915,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
                     for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             kt = 0;
             tile += G;
+            PP_TRACE(1);
+            if (wm == 1) __builtin_amdgcn_s_barrier();
+#ifdef MMAE_PP_TRACE
+            ++trace_tile;
+#endif
         }
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();  // pairs with the extra barrier of the second group
@@ -901,6 +1077,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_p2_kernel(GemmNT p, int tiles_
     char* const a_ring = p2smem;
     char* const w_ring = p2smem + 3 * P2_A_BYTES;
     float* bias_lds = (float*)(p2smem + 3 * P2_A_BYTES + 3 * P2_W_BYTES) + wave * 64;
+    if (!p.bias) bias_lds[lane] = 0.f;
 
     auto tile_origin = [&](int t, int& m0, int& n0) {  // groups of 8 row-tiles x all column-tiles, rows fastest
         const int per_group = 8 * tiles_n;
@@ -1066,14 +1243,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_p2_kernel(GemmNT p, int tiles_
         if (++kt == nk) {
             int m0, n0;
             tile_origin(tile, m0, n0);
-            float bv[16];
-            if (p.bias) {
+            float bv[16];  // the wave's bias slice (zeros without a bias: written once at the start)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const f32x4 b0 = *(const f32x4*)(bias_lds + 32 * u + 8 * fq), b1 = *(const f32x4*)(bias_lds + 32 * u + 8 * fq + 4);
+            for (int u = 0; u < 2; ++u) {
+                const f32x4 b0 = *(const f32x4*)(bias_lds + 32 * u + 8 * fq), b1 = *(const f32x4*)(bias_lds + 32 * u + 8 * fq + 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { bv[8 * u + e] = b0[e]; bv[8 * u + 4 + e] = b1[e]; }
-                }
+                for (int e = 0; e < 4; ++e) { bv[8 * u + e] = b0[e]; bv[8 * u + 4 + e] = b1[e]; }
             }
             const bool full = m0 + 128 <= p.M && n0 + 256 <= p.N;  // workgroup-uniform
             if constexpr (EPI == EPI_DGELU) {

@@ -34,6 +34,17 @@ if __name__ == "__main__":
                  ("L fc1+gelu", 18496, 4096, 1024, 1), ("L dgelu", 18496, 4096, 1024, 3), ("L qkv", 18496, 3072, 1024, 0)]
     if only == "dec":
         shapes_nt = [t for t in shapes_nt if t[0].startswith("dec") or t[0].startswith("L ")]
+    if only == "pp":  # the 256x256 kernel alone, at the shapes it is taken for
+        for name, m, n, k, epi in shapes_nt:
+            if name.startswith("dec") or name == "pctx":
+                continue
+            a, w = r(m, k), r(n, k)
+            bias = torch.randn(n, device="cuda")
+            aux = r(m, n, dt=torch.float32) if epi == 2 else (r(m, n) if epi == 3 else None)
+            ops._L().mmae_gemm_nt_set_variant(5)
+            t = timeit(lambda: ops.gemm_nt(epi, a, w, None if epi == 3 else bias, aux=aux), iters=30)
+            print(f"pp256 {name:12s} M={m} N={n} K={k}: {t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
+        sys.exit(0)
     for name, m, n, k, epi in shapes_nt:
         a, w = r(m, k), r(n, k)
         bias = torch.randn(n, device="cuda")

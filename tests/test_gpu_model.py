@@ -467,7 +467,9 @@ def test_checkpoint_round_trip_and_optimizer_interchange(tmp_path):
     assert step4.opt.step_count == 3
     l3, _, _ = step(x, mask_randomness=rnd)
     l4, _, _ = step4(x, mask_randomness=rnd)
-    assert abs(l3.item() - l4.item()) / abs(l3.item()) < 1e-4
+    # two parameter sets 2e-5 apart, each through its own bf16 forward: the losses agree to the rounding noise of that
+    # forward (a few 1e-4 on this 4-image batch), not to the distance of the parameters
+    assert abs(l3.item() - l4.item()) / abs(l3.item()) < 5e-4
 
     exp = torch.load(CK.save_model_for_downstream_tasks(str(tmp_path), "run", 4, model), map_location="cpu", weights_only=True)
     assert list(exp) == ["model"] and not any(k.startswith("output_adapters.") for k in exp["model"])
