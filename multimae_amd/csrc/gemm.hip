@@ -1360,9 +1360,10 @@ static int launch_nt(const GemmNT& p, hipStream_t s) {
             const char* e = getenv("MMAE_PP_FILL");
             env_fill = e ? atof(e) : 0.0;
         }
-        // long reductions amortise the tile start-up and the second launch better (measured at N = 768, M = 25344,
-        // fill 0.66: K = 3072 wins by 4-10 % over the 128x128 kernel, K = 768 loses by 5 %)
-        const double min_fill = env_fill > 0.0 ? env_fill : (p.K >= 2048 ? 0.65 : 0.75);
+        // with the two groups' epilogues side by side the 256x256 kernel wins down to a third of the CUs' rounds filled
+        // (M = 25344: N = 768, K = 768, fill 0.66: 57 against 64 us with the residual epilogue, 38 against 42 us without;
+        // N = 256, K = 768, fill 0.39: 15 against 17 us)
+        const double min_fill = env_fill > 0.0 ? env_fill : 0.35;
         if (fill >= min_fill) { g_last_nt = 5; return launch_nt_pp<EPI>(p, s); }
     }
     if (g_nt_variant == 4 || (g_nt_variant == 0 && p.N >= 2048 && tiles128 >= 4 * 2 * num_cus())) {
@@ -1756,20 +1757,31 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(GemmTN p, int tiles_
     if (wn == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    float* out = p.out + (long)split * p.slab;
+    // The wave's 128 x 64 block leaves through the (now idle) operand ring, 64 rows x 256 bytes at a time, so that a store
+    // instruction covers four whole 256-byte rows: in the accumulator layout the sixteen lanes i16 hold sixteen different
+    // rows, 64 separate segments per instruction, about a quarter of the store rate of a CU.  Chunk c (16 bytes) of row r
+    // sits at c ^ (r & 15) in the wave's 16-KiB piece: no bank conflicts in either direction; DS operations of a wave
+    // execute in order, and the piece is private to the wave (the loads into the ring were waited for above, by every
+    // wave of its own, and the other group no longer reads the ring once it is past its last cluster's reads:
+    // the barrier below).
+    __builtin_amdgcn_s_barrier();
+    float* out = p.out + (long)split * p.slab + (long)(n0 + wn * 128) * p.K + k0 + wk * 64;
+    char* piece = tnsmem + wave * 16384;
+    const int rr = lane >> 4, cc = lane & 15;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 128 + h * 64 + ni * 16 + i16;
-            if (n >= p.N) continue;
+        for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int ki = 0; ki < 4; ++ki) {
-                const int k = k0 + wk * 64 + ki * 16 + g * 4;
-                if (k >= p.K) continue;
-                *(f32x4*)(out + (long)n * p.K + k) = acc[h][ki][ni];
-            }
+            for (int ki = 0; ki < 4; ++ki)
+                *(f32x4*)(piece + (ni * 16 + i16) * 256 + (((ki * 4 + g) ^ i16) << 4)) = acc[h][ki][ni];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int r = 4 * j + rr;
+            const f32x4 v = *(const f32x4*)(piece + r * 256 + ((cc ^ (r & 15)) << 4));
+            *(f32x4*)(out + (long)(h * 64 + r) * p.K + 4 * cc) = v;
         }
+    }
     if (do_colsum) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
