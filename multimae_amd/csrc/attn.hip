@@ -38,18 +38,6 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& t, int s) {
     return r;
 }
 
-// acc + sum of the eight bf16 values of a packed fragment: four v_dot2c_f32_bf16 against (1, 1) instead of eight
-// widen-and-add pairs (the row sum of dS has to be taken over the rounded values the MFMA sees)
-__device__ __forceinline__ float add_bf16x8(float acc, const bf16x8& v) {
-    typedef __attribute__((ext_vector_type(2))) bf16 bf16x2;
-    const bf16x2 ones = {(bf16)1.0f, (bf16)1.0f};
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 0, 1), ones, acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 2, 3), ones, acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 4, 5), ones, acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 6, 7), ones, acc, false);
-    return acc;
-}
-
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 a;
 #pragma unroll

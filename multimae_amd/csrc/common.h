@@ -60,6 +60,18 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
+// acc + sum of the eight bf16 values of a packed fragment: four v_dot2c_f32_bf16 against (1, 1) instead of eight
+// widen-and-add pairs (the row sum of dS has to be taken over the rounded values the MFMA sees)
+__device__ __forceinline__ float add_bf16x8(float acc, const bf16x8& v) {
+    typedef __attribute__((ext_vector_type(2))) bf16 bf16x2;
+    const bf16x2 ones = {(bf16)1.0f, (bf16)1.0f};
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 0, 1), ones, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 2, 3), ones, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 4, 5), ones, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 6, 7), ones, acc, false);
+    return acc;
+}
+
 // erf-form GELU for GEMM epilogues.  erf(z) = sign(z) * (1 - P(t) * exp(-z^2)), t = 1 / (1 + p|z|)
 // (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7, far below the bf16 rounding of the result): one rcp, one exp and
 // six FMAs per element instead of the ~100-instruction branchy libm erff, which made the epilogue longer than the main loop.

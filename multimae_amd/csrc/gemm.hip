@@ -1666,7 +1666,16 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(GemmTN p, int tiles_
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(off + 1024));
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
-    const bool do_colsum = p.colsum != nullptr && k0 == 0;
+    // Bias gradient: the column sums of the X tile, taken on the vector ALU from the fragments already in registers.  The
+    // tiles_k workgroups that share an X tile share the work: fragment f = 2 wk + t (of the eight 16-column fragments a
+    // wave row holds; all four wk waves hold the same ones) belongs to the workgroup with k-tile index f % min(tiles_k, 8).
+    // Left to the k-tile-0 workgroups alone it made them (a third of the grid at K = 768) 11 % slower than the rest, and
+    // the launch as slow as them.
+    const int cs_share = tiles_k < 8 ? tiles_k : 8, cs_kt = tile % tiles_k;
+    bool cs_mine[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) cs_mine[t] = p.colsum != nullptr && (wk * 2 + t) % cs_share == cs_kt;
+    const bool do_colsum = cs_mine[0] || cs_mine[1];
     float cs[2] = {0.f, 0.f};  // column sums of X fragments ni = (wk & 1) * 2 + {0, 1} of X half (wk >> 1)
     auto read_x = [&](unsigned lb, auto slot_c) {
         constexpr int so = decltype(slot_c)::value * PP_H_BYTES;
@@ -1680,11 +1689,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(GemmTN p, int tiles_
         if (do_colsum && (wk >> 1) == half) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
+                if (cs_mine[t]) {
 #pragma unroll
-                for (int ms = 0; ms < 2; ++ms) {
-                    const bf16x8 v = (wk & 1) ? xf[2 + t][ms] : xf[t][ms];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) cs[t] += (float)v[e];
+                    for (int ms = 0; ms < 2; ++ms) cs[t] = add_bf16x8(cs[t], (wk & 1) ? xf[2 + t][ms] : xf[t][ms]);
                 }
         }
     };
@@ -1789,7 +1796,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pp_kernel(GemmTN p, int tiles_
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
             const int n = n0 + wn * 128 + (wk >> 1) * 64 + ((wk & 1) * 2 + t) * 16 + i16;
-            if (g == 0 && n < p.N) p.colsum[(long)split * p.N + n] = v;
+            if (cs_mine[t] && g == 0 && n < p.N) p.colsum[(long)split * p.N + n] = v;
         }
     }
 }

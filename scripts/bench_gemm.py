@@ -74,10 +74,17 @@ if __name__ == "__main__":
             ops._L().mmae_gemm_tn_set_variant(variant)
             t = timeit(lambda: ops.gemm_tn(x, y, out=out, accumulate=True, colsum_out=cs, colsum_accumulate=True))
             res.append(f"{t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
+        ops._L().mmae_gemm_tn_set_variant(2)
+        t = timeit(lambda: ops.gemm_tn(x, y, out=out, accumulate=True))
+        res.append(f"{t*1e6:8.1f} us")
+        ops._L().mmae_gemm_tn_set_phase(1)
+        t = timeit(lambda: ops.gemm_tn(x, y, out=out, accumulate=True, colsum_out=cs, colsum_accumulate=True))
+        res.append(f"{t*1e6:8.1f} us")
+        ops._L().mmae_gemm_tn_set_phase(0)
         ops._L().mmae_gemm_tn_set_variant(0)
         o2 = torch.empty(n, k, device="cuda", dtype=torch.bfloat16)
         t = timeit(lambda: torch.matmul(x.t(), y, out=o2))  # yardstick: vendor library, bf16 output, no column sums
-        print(f"gemm_tn {name:10s} M={m} N={n} K={k}: t128 {res[0]} | pp256 {res[1]} | vendor plain {t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
+        print(f"gemm_tn {name:10s} M={m} N={n} K={k}: t128 {res[0]} | pp256 {res[1]} | pp256 without column sums {res[2]} | pp256 kernel alone {res[3]} | vendor plain {t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
     for name, B, H, nq, nk, d in [("enc", 256, 12, 99, 99, 64), ("dec self", 256, 8, 196, 196, 32), ("dec cross", 256, 8, 196, 99, 32)]:
         if nq == nk:
             qkv = r(B * nq, 3 * H * d); q, k_, v = qkv[:, :H*d], qkv[:, H*d:2*H*d], qkv[:, 2*H*d:]
