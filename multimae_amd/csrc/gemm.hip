@@ -8,6 +8,9 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
+#ifndef MMAE_RES_AHEAD
+#define MMAE_RES_AHEAD 3  // pieces of the residual fetched ahead of the stores in the row-major epilogue (tuning builds override it)
+#endif
 
 #define BM 128
 #define BN 128
@@ -297,7 +300,7 @@ __device__ __forceinline__ void store_wave_tile_rows(const GemmNT& p, const f32x
         }
     } else {
         // pieces in the order (mi, u): 16 rows x 32 fp32 columns
-        constexpr int RES_AHEAD = 3;
+        constexpr int RES_AHEAD = MMAE_RES_AHEAD;
         float* const o0 = (float*)p.out + (long)(mw + rr) * p.ldo + nw + 4 * cc;
         const float* const a0 = EPI == EPI_RESID ? (const float*)p.aux + (long)(mw + rr) * p.ldaux + nw + 4 * cc : nullptr;
         char* const w0 = wrow + (((2 * fq) ^ wsw) << 4);
