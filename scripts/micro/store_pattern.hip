@@ -65,6 +65,8 @@ int main() {
     run<3>(buf, "accumulator layout, 8 B");
     for (int g : {8, 16, 32, 64, 128, 192}) run<0>(buf, "accumulator layout, 16 B", g);
     for (int g : {8, 32, 128}) run<1>(buf, "8 rows x 128 B", g);
+    for (int g : {8, 32, 128}) run<2>(buf, "16 rows x 64 B, quads contiguous", g);
+    for (int g : {8, 32}) run<3>(buf, "accumulator layout, 8 B", g);
     hipFree(buf);
     return 0;
 }
