@@ -57,20 +57,43 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* X, int ldr, int n0, int dd
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// stage rows [0, n_valid) of a [len, D] slice (row stride ld) into a row-major LDS image [n_pad][D + 8], zero-filled tail
-template <int D>
-__device__ __forceinline__ void stage_rows(const bf16* src, long ld, int n_valid, int n_pad, bf16* img, int tid, int nthreads) {
+// Two [len, D] slices that share the row count (K and V, or Q and dO; row strides lda / ldb) into row-major LDS images
+// [n_pad][D + 8] with a zero-filled tail: U chunks of each requested before the first
+// LDS store and no branch between the requests (rows past the end are fetched from the last row and zeroed afterwards): one
+// trip to memory per U * nthreads chunks instead of one per chunk and slice
+template <int D, int U>
+__device__ __forceinline__ void stage_rows2(const bf16* a, long lda, const bf16* b, long ldb, int n_valid, int n_pad, bf16* img_a, bf16* img_b,
+                                            int tid, int nthreads) {
     constexpr int CH = D / 8, LDR = D + 8;
-    for (int idx = tid; idx < n_pad * CH; idx += nthreads) {
-        const int n = idx / CH, c = idx - n * CH;
-        bf16x8 v;
-        if (n < n_valid) v = *(const bf16x8*)(src + (long)n * ld + c * 8);
-        else {
+    for (int base = tid; base < n_pad * CH; base += U * nthreads) {
+        bf16x8 va[U], vb[U];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * nthreads, n = idx / CH, c = idx - n * CH;
+            const long nc = n < n_valid ? n : n_valid - 1;
+            va[u] = *(const bf16x8*)(a + nc * lda + c * 8);
+            vb[u] = *(const bf16x8*)(b + nc * ldb + c * 8);
         }
-        *(bf16x8*)(img + n * LDR + c * 8) = v;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * nthreads, n = idx / CH, c = idx - n * CH;
+            if (idx < n_pad * CH) {
+                const bool ok = n < n_valid;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { va[u][e] = ok ? va[u][e] : (bf16)0.f; vb[u][e] = ok ? vb[u][e] : (bf16)0.f; }
+                *(bf16x8*)(img_a + n * LDR + c * 8) = va[u];
+                *(bf16x8*)(img_b + n * LDR + c * 8) = vb[u];
+            }
+        }
     }
+}
+
+// U chosen so that a round does not fetch more than it stores: two chunks per thread and slice where that covers the image
+template <int D>
+__device__ __forceinline__ void stage_pair(const bf16* a, long lda, const bf16* b, long ldb, int n_valid, int n_pad, bf16* img_a, bf16* img_b,
+                                           int tid, int nthreads) {
+    if (n_pad * (D / 8) <= 2 * nthreads) stage_rows2<D, 2>(a, lda, b, ldb, n_valid, n_pad, img_a, img_b, tid, nthreads);
+    else stage_rows2<D, 4>(a, lda, b, ldb, n_valid, n_pad, img_a, img_b, tid, nthreads);
 }
 
 // row fragment (A or B operand with the row index on the lane) of a row-major image
@@ -102,8 +125,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p, int nkp) 
     const int r = lane & 31, h2 = lane >> 5;
     const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
 
-    stage_rows<D>(p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.kv_len, nkp, Ks, tid, NW * 64);
-    stage_rows<D>(p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.kv_len, nkp, Vs, tid, NW * 64);
+    // every kernel argument in registers before the first branch (otherwise the pointers are fetched behind it: a second
+    // scalar round trip before the first load of a workgroup that lives about 15 us)
+    asm volatile("" ::"s"(p.q), "s"(p.k), "s"(p.v), "s"(p.o), "s"(p.lse), "s"(p.ldq), "s"(p.ldk), "s"(p.ldv), "s"(p.ldo));
+    stage_pair<D>(p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.kv_len, nkp, Ks, Vs,
+                  tid, NW * 64);
     __syncthreads();
 
     const float c = p.scale * LOG2E;
@@ -218,8 +244,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs p, int nk
     const int r = lane & 31, h2 = lane >> 5;
     const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
 
-    stage_rows<D>(p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.kv_len, nkp, Ks, tid, NW * 64);
-    stage_rows<D>(p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.kv_len, nkp, Vs, tid, NW * 64);
+    stage_pair<D>(p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.kv_len, nkp, Ks, Vs,
+                  tid, NW * 64);
     __syncthreads();
     if (tid < D) {
         float sum = 0.f;
@@ -322,8 +348,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs p, int n
     const int r = lane & 31, h2 = lane >> 5;
     const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
 
-    stage_rows<D>(p.q + (long)b * p.q_len * p.ldq + h * D, p.ldq, p.q_len, nqp, Qs, tid, NW * 64);
-    stage_rows<D>(p.dO + (long)b * p.q_len * p.lddo + h * D, p.lddo, p.q_len, nqp, dOs, tid, NW * 64);
+    stage_pair<D>(p.q + (long)b * p.q_len * p.ldq + h * D, p.ldq, p.dO + (long)b * p.q_len * p.lddo + h * D, p.lddo, p.q_len, nqp, Qs, dOs,
+                  tid, NW * 64);
     for (int n = tid; n < nqp; n += NW * 64) {
         const bool ok = n < p.q_len;
         lse2[n] = ok ? p.lse[((long)b * p.H + h) * p.q_len + n] * LOG2E : 1e30f;
@@ -400,6 +426,17 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs p, int n
 // by the 32-key dK / dV tiles, dealt round-robin to the waves: same arithmetic as the two kernels above, every fragment
 // from LDS.
 // --------------------------------------------------------------------------------------------
+#ifdef MMAE_ATTN_TRACE
+// timing build only: per workgroup (first 1024) and wave, 100 MHz timestamps: 0 start, 1 staged, 2 items done,
+// 3 loads issued, 4 loads landed and stored, 5 past the first barrier
+__device__ unsigned long long g_attn_trace[1024 * 8 * 8];
+extern "C" int mmae_debug_attn_trace(void* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_trace), sizeof(g_attn_trace)) == hipSuccess ? 0 : 1;
+}
+#define ATTN_TRACE(slot) do { if (blockIdx.x < 1024 && (threadIdx.x & 63) == 0) g_attn_trace[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define ATTN_TRACE(slot) do {} while (0)
+#endif
 template <int D, int NW>
 __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, int nqp, int nkp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -417,40 +454,102 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h2 = lane >> 5;
     const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+    ATTN_TRACE(0);
 
-    stage_rows<D>(p.q + (long)b * p.q_len * p.ldq + h * D, p.ldq, p.q_len, nqp, Qs, tid, NW * 64);
-    stage_rows<D>(p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.kv_len, nkp, Ks, tid, NW * 64);
-    stage_rows<D>(p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.kv_len, nkp, Vs, tid, NW * 64);
-    // dO with delta: CH adjacent lanes hold one row (nqp * CH is a multiple of 64, so whole waves run each iteration)
-    for (int idx = tid; idx < nqp * CH; idx += NW * 64) {
-        const int n = idx / CH, ch = idx - n * CH;
-        bf16x8 g;
-        float part = 0.f;
-        if (n < p.q_len) {
-            g = *(const bf16x8*)(p.dO + ((long)b * p.q_len + n) * p.lddo + h * D + ch * 8);
-            const bf16x8 of = *(const bf16x8*)(p.o + ((long)b * p.q_len + n) * p.ldo + h * D + ch * 8);
+    // Staging: every 16-byte chunk of Q, dO, O, K and V that this thread moves in a round (two per operand: one round for
+    // up to 128 rows at head_dim 64 with 512 threads) is requested before the first one is stored to LDS, so a round costs
+    // one trip to memory instead of one per operand and loop iteration (ten dependent trips at the pretraining shapes,
+    // about half of the workgroup's lifetime).  CH adjacent lanes hold one row (nqp * CH and nkp * CH are multiples of 64,
+    // so whole waves run each round); delta = rowsum(dO * O) is formed on the way; the column sums of K (for kbar) are
+    // taken from the chunks in registers: a thread's chunk column is the same in every round.
+    {
+        constexpr int U = 2, NT = NW * 64;
+        static_assert(NT % CH == 0, "a thread keeps its chunk column across rounds");
+        const bf16* qg = p.q + (long)b * p.q_len * p.ldq + h * D;
+        const bf16* kg = p.k + (long)b * p.kv_len * p.ldk + h * D;
+        const bf16* vg = p.v + (long)b * p.kv_len * p.ldv + h * D;
+        const bf16* dog = p.dO + (long)b * p.q_len * p.lddo + h * D;
+        const bf16* og = p.o + (long)b * p.q_len * p.ldo + h * D;
+        const int ch = tid % CH;
+        float ksum[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) part += (float)g[e] * (float)of[e];
-        } else {
+        for (int e = 0; e < 8; ++e) ksum[e] = 0.f;
+        const int nmax = nqp > nkp ? nqp : nkp;
+        for (int base = tid; base < nmax * CH; base += U * NT) {
+            bf16x8 vq[U], vdo[U], vo[U], vk[U], vv[U];
+            float vl[U];
+            // rows past the end are fetched from the last row and zeroed afterwards: no branch between the loads, so all ten
+            // are in flight together (a branch join waits for every load issued before it)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) g[e] = (bf16)0.f;
+            for (int u = 0; u < U; ++u) {
+                const int n = (base + u * NT) / CH;
+                const long nq_c = n < p.q_len ? n : p.q_len - 1, nk_c = n < p.kv_len ? n : p.kv_len - 1;
+                vk[u] = *(const bf16x8*)(kg + nk_c * p.ldk + ch * 8);
+                vv[u] = *(const bf16x8*)(vg + nk_c * p.ldv + ch * 8);
+                vq[u] = *(const bf16x8*)(qg + nq_c * p.ldq + ch * 8);
+                vdo[u] = *(const bf16x8*)(dog + nq_c * p.lddo + ch * 8);
+                vo[u] = *(const bf16x8*)(og + nq_c * p.ldo + ch * 8);
+                vl[u] = p.lse[((long)b * p.H + h) * p.q_len + nq_c];  // with the operands: fetched after them it is a second trip
+            }
+            ATTN_TRACE(3);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int n = (base + u * NT) / CH;
+                const bool qv = n < p.q_len, kv = n < p.kv_len;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    vk[u][e] = kv ? vk[u][e] : (bf16)0.f; vv[u][e] = kv ? vv[u][e] : (bf16)0.f;
+                    vq[u][e] = qv ? vq[u][e] : (bf16)0.f; vdo[u][e] = qv ? vdo[u][e] : (bf16)0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int n = (base + u * NT) / CH;
+                if (n < nkp) {
+                    *(bf16x8*)(Ks + n * LDR + ch * 8) = vk[u];
+                    *(bf16x8*)(Vs + n * LDR + ch * 8) = vv[u];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ksum[e] += (float)vk[u][e];
+                }
+                if (n < nqp) {  // wave-uniform: n differs by at most 64 / CH rows inside a wave and nqp is a multiple of 32 >= that
+                    *(bf16x8*)(Qs + n * LDR + ch * 8) = vq[u];
+                    *(bf16x8*)(dOs + n * LDR + ch * 8) = vdo[u];
+                    float part = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) part += (float)vdo[u][e] * (float)vo[u][e];
+#pragma unroll
+                    for (int m = 1; m < CH; m <<= 1) part += __shfl_xor(part, m, 64);
+                    if (ch == 0) {
+                        delta[n] = -part * p.scale;  // kept negated and scaled: dS = P * fma(dP, scale, delta), one instruction fewer per score
+                        lse2[n] = n < p.q_len ? vl[u] * LOG2E : 1e30f;  // padded rows: every probability 0
+                    }
+                }
+            }
         }
-        *(bf16x8*)(dOs + n * LDR + ch * 8) = g;
+        ATTN_TRACE(4);
+        // kbar: lanes with the same chunk column (lane % CH) across the wave, then across the waves through LDS
 #pragma unroll
-        for (int m = 1; m < CH; m <<= 1) part += __shfl_xor(part, m, 64);
-        if (ch == 0) {
-            delta[n] = -part * p.scale;  // kept negated and scaled: dS = P * fma(dP, scale, delta), one instruction fewer per score
-            lse2[n] = n < p.q_len ? p.lse[((long)b * p.H + h) * p.q_len + n] * LOG2E : 1e30f;  // padded rows: every probability 0
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int m = CH; m < 64; m <<= 1) ksum[e] += __shfl_xor(ksum[e], m, 64);
         }
+        float* kpart = (float*)(kbar + D);  // [NW][D] partial sums
+        if (lane < CH) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kpart[wave * D + lane * 8 + e] = ksum[e];
+        }
+        __syncthreads();
+        ATTN_TRACE(5);
+        if (tid < D) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += kpart[w * D + tid];
+            kbar[tid] = sum / (float)p.kv_len;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (tid < D) {
-        float sum = 0.f;
-        for (int n = 0; n < p.kv_len; ++n) sum += (float)Ks[n * LDR + tid];
-        kbar[tid] = sum / (float)p.kv_len;
-    }
-    __syncthreads();
 
+    ATTN_TRACE(1);
     const float c = p.scale * LOG2E;
     const int nqt = nqp / 32, nkt = nkp / 32;
     const int tail = p.kv_len - (nkt - 1) * 32;
@@ -599,6 +698,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, 
             }
         }
     }
+    ATTN_TRACE(2);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -649,7 +749,8 @@ static thread_local int g_bwd_variant = 0;  // 0 = by size, 1 = two kernels, 2 =
 extern "C" void mmae_attn_bwd_set_variant(int v) { g_bwd_variant = v; }
 
 static size_t fused_lds_bytes(const AttnArgs& a, int D) {
-    return sizeof(bf16) * 2 * (size_t)(pad32(a.q_len) + pad32(a.kv_len)) * (D + 8) + sizeof(float) * (2 * pad32(a.q_len) + D);
+    // Q, dO, K, V images; lse and delta per query; the mean key and its per-wave partial sums (8 waves)
+    return sizeof(bf16) * 2 * (size_t)(pad32(a.q_len) + pad32(a.kv_len)) * (D + 8) + sizeof(float) * (2 * pad32(a.q_len) + D + 8 * D);
 }
 template <int D, int NW>
 static int launch_fused(const AttnArgs& a, hipStream_t s) {
