@@ -1344,11 +1344,13 @@ static int launch_nt(const GemmNT& p, hipStream_t s) {
     if constexpr (EPI != EPI_TOKENS && EPI != EPI_UNPATCH) {
         if (g_nt_variant == 7 && p.K % 64 == 0 && p.K >= 128) { g_last_nt = 7; return launch_nt_p2<EPI>(p, s); }
     }
-    if constexpr (EPI == EPI_GELU || EPI == EPI_DGELU) {
-        // Short reductions under an epilogue that moves a second matrix (the decoders' fc1 + GELU and its backward,
-        // K = 256): the tile time is mostly epilogue, which the two workgroups per CU of the 128x256 kernel overlap
-        // (M = 50176, N = 1024: 78 -> 62 us and 85 -> 65 us).  Its main loop is the slower one, so long reductions stay
-        // with the 256x256 kernel (K = 768: 157 against 174 us).
+    if constexpr (EPI == EPI_DGELU) {
+        // Short reductions under the GELU' epilogue (the decoders' fc1 backward, K = 256): the tile time is mostly epilogue,
+        // which the two workgroups per CU of the 128x256 kernel overlap.  Measured with operands that come from HBM, as
+        // inside the step (scripts/bench_gemm.py cold), M = 50176, N = 1024: 74.5 us against 77.4 (256x256) and 76.2
+        // (128x128).  The forward (GELU, two outputs) is the other way round since the 256x256 kernel runs its two
+        // epilogues side by side: 65.7 against 72.3 us.  Long reductions stay with the 256x256 kernel (its main loop is
+        // the faster one: K = 768, 140 against 166 us).
         const long tiles_p2 = (long)((p.M + 127) / 128) * ((p.N + 255) / 256);
         if (g_nt_variant == 0 && p.K % 64 == 0 && p.K >= 128 && p.K <= 256 && p.N >= 512 && tiles_p2 >= 2 * num_cus()) {
             g_last_nt = 7;

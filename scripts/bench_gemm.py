@@ -34,6 +34,30 @@ if __name__ == "__main__":
                  ("L fc1+gelu", 18496, 4096, 1024, 1), ("L dgelu", 18496, 4096, 1024, 3), ("L qkv", 18496, 3072, 1024, 0)]
     if only == "dec":
         shapes_nt = [t for t in shapes_nt if t[0].startswith("dec") or t[0].startswith("L ")]
+    if only == "cold":  # operands rotated through more than the 256-MB Infinity Cache: what a launch inside the step sees
+        for name, m, n, k, epi in shapes_nt:
+            if not (name.startswith("dec") or name in ("pctx", "qkv", "dA proj", "proj+res")):
+                continue
+            per = (m * k + (m * n) * (2 if epi in (2, 4) else 1) * (2 if epi == 1 else 1) + (m * n * (2 if epi == 2 else 1) if epi in (2, 3) else 0)) * 2
+            copies = max(2, int(600e6 // per) + 1)
+            As = [r(m, k) for _ in range(copies)]
+            w = r(n, k)
+            bias = torch.randn(n, device="cuda")
+            auxs = [(r(m, n, dt=torch.float32) if epi == 2 else (r(m, n) if epi == 3 else None)) for _ in range(copies)]
+            outs = [torch.empty(m, n, device="cuda", dtype=torch.float32 if epi in (2, 4) else torch.bfloat16) for _ in range(copies)]
+            outs2 = [torch.empty(m, n, device="cuda", dtype=torch.bfloat16) if epi == 1 else None for _ in range(copies)]
+            res = []
+            for variant in (1, 5, 7, 0):
+                ops._L().mmae_gemm_nt_set_variant(variant)
+                it = [0]
+                def call():
+                    i = it[0] % copies; it[0] += 1
+                    ops.gemm_nt(epi, As[i], w, None if epi == 3 else bias, aux=auxs[i], out=outs[i])
+                t = timeit(call, iters=4 * copies)
+                res.append(f"{t*1e6:7.1f} us")
+            ops._L().mmae_gemm_nt_set_variant(0)
+            print(f"cold {name:12s} M={m} N={n} K={k} ({copies} operand sets): t128 {res[0]} | pp256 {res[1]} | 2wg128x256 {res[2]} | auto {res[3]}")
+        sys.exit(0)
     if only == "pp":  # the 256x256 kernel alone, at the shapes it is taken for
         for name, m, n, k, epi in shapes_nt:
             if name.startswith("dec") or name == "pctx":
