@@ -210,7 +210,7 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
     y = torch.empty(x.shape, dtype=BF16, device=x.device)
     mean = torch.empty((rows,), dtype=F32, device=x.device)
     rstd = torch.empty((rows,), dtype=F32, device=x.device)
-    with _Timed("layernorm_fwd", 0.0, "layernorm_fwd_kernel", nbytes=rows * (6 * dim + 8) + 8 * dim):  # x in; y, mean, rstd out
+    with _Timed("layernorm_fwd", 0.0, "layernorm_fwd_rows_kernel", nbytes=rows * (6 * dim + 8) + 8 * dim):  # x in; y, mean, rstd out
         _lib.check(_L().mmae_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), rows, dim, eps,
                                            _stream()), "layernorm_fwd")
     return y, mean, rstd
