@@ -101,40 +101,44 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // GELU and its derivative on the packed fp32 ALU, without transcendentals.  Both Phi(x) - 1/2 and gelu'(x) - 1/2 are odd
 // functions: x * P(u) with u = x^2 scaled to [-1, 1] (least squares on Chebyshev nodes, scripts/fit_gelu_poly.py), fitted
 // under the condition that the value at the end of the range is exactly 1/2: the argument is clamped to the range and the
-// saturated branches (+-1/2 beyond |x| = 4, 4.5) need no select.  Absolute error <= 3.4e-5 (6.9e-5), below the bf16
+// saturated branches (+-1/2 beyond |x| = 4, 4.5) need no select.  Absolute error <= 3.8e-5 (6.9e-5), below the bf16
 // rounding of the stored result for every value that matters; a GEMM epilogue with the rcp/exp2 form spent a quarter of the
 // tile time here.  NP pairs are evaluated side by side, coefficient by coefficient: a dependent chain of packed FMAs costs
 // a wait state per link, independent chains fill them.
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-template <int NP, int NC>
-__device__ __forceinline__ void odd_poly2(const f32x2 (&x)[NP], f32x2 (&r)[NP], const float (&c)[NC], float inv_half_range, float xmax) {
-    f32x2 xc[NP], u[NP];
+// r = xc * P(w) + 1/2 with xc = clamp(x, -xmax, xmax) and w = xc^2 * scale + shift (scale = 1, shift = 0: P is given in x^2
+// itself, one instruction fewer; accurate enough in fp32 for the degree-7 polynomial of GELU, not for the degree-9 one of
+// its derivative, which keeps the argument scaled to [-1, 1])
+template <int NP, int NC, bool SCALED>
+__device__ __forceinline__ void odd_poly2_half(const f32x2 (&x)[NP], f32x2 (&r)[NP], const float (&c)[NC], float scale, float xmax) {
+    f32x2 xc[NP], w[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         xc[i] = (f32x2){__builtin_amdgcn_fmed3f(x[i][0], -xmax, xmax), __builtin_amdgcn_fmed3f(x[i][1], -xmax, xmax)};
-        u[i] = xc[i] * xc[i] * inv_half_range - 1.0f;
+        w[i] = xc[i] * xc[i];
+        if (SCALED) w[i] = w[i] * scale - 1.0f;
         r[i] = (f32x2){c[NC - 1], c[NC - 1]};
     }
 #pragma unroll
     for (int k = NC - 2; k >= 0; --k)
 #pragma unroll
-        for (int i = 0; i < NP; ++i) r[i] = r[i] * u[i] + c[k];
+        for (int i = 0; i < NP; ++i) r[i] = r[i] * w[i] + c[k];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) r[i] = xc[i] * r[i];
+    for (int i = 0; i < NP; ++i) r[i] = xc[i] * r[i] + 0.5f;
 }
 template <int NP>
 __device__ __forceinline__ void gelu_poly2(const f32x2 (&x)[NP], f32x2 (&g)[NP]) {  // x * Phi(x)
-    const float c[8] = {0.1759425550699234f, -0.084359310567379f, 0.05620153620839119f, -0.0365694984793663f, 0.021034933626651764f, -0.012868070974946022f, 0.008746585808694363f, -0.0031287299934774637f};
-    odd_poly2<NP, 8>(x, g, c, 2.0f / 16.0f, 4.0f);
+    // in x^2 (scripts/fit_gelu_poly.py: the fit in u = x^2 / 8 - 1 re-expanded in double precision)
+    const float c[8] = {0.398851215839386f, -0.066166453063488f, 0.009651601314544678f, -0.0010426313383504748f,
+                        7.960928633110598e-05f, -3.9993565223994665e-06f, 1.1691168566585475e-07f, -1.4918947188746756e-09f};
+    odd_poly2_half<NP, 8, false>(x, g, c, 1.0f, 4.0f);
 #pragma unroll
-    for (int i = 0; i < NP; ++i) g[i] = x[i] * (g[i] + 0.5f);
+    for (int i = 0; i < NP; ++i) g[i] = x[i] * g[i];
 }
 template <int NP>
 __device__ __forceinline__ void gelu_grad_poly2(const f32x2 (&x)[NP], f32x2 (&d)[NP]) {  // Phi(x) + x * phi(x)
     const float c[10] = {0.15944573283195496f, -0.08991280198097229f, 0.0861779972910881f, -0.09547753632068634f, 0.10513326525688171f, -0.08748847991228104f, 0.04747903347015381f, -0.04563887044787407f, 0.05615197867155075f, -0.024759210646152496f};
-    odd_poly2<NP, 10>(x, d, c, 2.0f / 20.25f, 4.5f);
-#pragma unroll
-    for (int i = 0; i < NP; ++i) d[i] = d[i] + 0.5f;
+    odd_poly2_half<NP, 10, true>(x, d, c, 2.0f / 20.25f, 4.5f);
 }
 
 // async 16-byte global -> LDS copy; `lds_wave_base` must be wave-uniform, lane i lands at +16*i

@@ -38,9 +38,18 @@ def evaluate(c, R, x):
 
 if __name__ == "__main__":
     xs = np.linspace(-8, 8, 400001)
-    for name, f, R, n in [("Phi(x) - 1/2 (gelu = x * (.. + 1/2))", lambda x: Phi(x) - 0.5, 4.0, 9),
-                          ("gelu'(x) - 1/2", lambda x: Phi(x) + x * phi(x) - 0.5, 4.5, 11)]:
+    for name, f, R, n in [("Phi(x) - 1/2 (gelu = x * (.. + 1/2))", lambda x: Phi(x) - 0.5, 4.0, 8),
+                          ("gelu'(x) - 1/2", lambda x: Phi(x) + x * phi(x) - 0.5, 4.5, 10)]:
         c = fit(f, R, n)
         err = np.abs(evaluate(c, R, xs).astype(np.float64) - (f(xs) + 0.5))
         print(f"{name}: R = {R}, {n} coefficients, max |error| = {err.max():.3g} at x = {xs[err.argmax()]:.3f}; value at -8: {evaluate(c, R, np.array([-8.0]))[0]:.3g}")
         print("  {" + ", ".join(f"{float(v)!r}f" for v in c) + "}")
+        # the same polynomial re-expanded in t = x^2 (double precision), evaluated in fp32 Horner form in t
+        ct = np.polynomial.Polynomial(c.astype(np.float64))(np.polynomial.Polynomial([-1.0, 2.0 / (R * R)])).coef
+        x32 = xs.astype(np.float32); xc = np.clip(x32, np.float32(-R), np.float32(R)); t = xc * xc
+        acc = np.full_like(x32, np.float32(ct[-1]))
+        for k in range(len(ct) - 2, -1, -1):
+            acc = acc * t + np.float32(ct[k])
+        err_t = np.abs((xc * acc + np.float32(0.5)).astype(np.float64) - (f(xs) + 0.5))
+        print(f"  in x^2: max |error| = {err_t.max():.3g}")
+        print("  {" + ", ".join(f"{float(np.float32(v))!r}f" for v in ct) + "}")
