@@ -90,6 +90,30 @@ def test_gemm_nt_strided_views(ops, nt_variant):
     assert outbuf[:, :512].abs().max().item() == 0
 
 
+def test_gemm_nt_epilogues_on_column_slices(ops, nt_variant):
+    """Every epilogue with its output, second output and epilogue input as column slices of wider buffers (row strides
+    different from N, two full 256-row panels and a ragged one), and the columns outside the slices left untouched."""
+    M, N, K = 700, 512, 256
+    a, w = _randn(M, K, seed=21), _randn(N, K, seed=22, scale=0.08)
+    bias = _randn(N, seed=23, dtype=torch.float32)
+    lin = a.float() @ w.float().t() + bias
+    resid_big = _randn(M, N + 256, seed=24, dtype=torch.float32)
+    out_big = torch.full((M, 2 * N), 7.0, dtype=torch.float32, device="cuda")
+    ops.gemm_nt(ops.EPI_RESID, a, w, bias, aux=resid_big[:, 256:], out=out_big[:, N:])
+    assert rel_err(out_big[:, N:], resid_big[:, 256:] + lin) < FP32_TOL
+    assert (out_big[:, :N] == 7.0).all()
+    h_big = _randn(M, N + 64, seed=25)
+    dg_big = torch.full((M, N + 128), 3.0, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(ops.EPI_DGELU, a, w, None, aux=h_big[:, 64:], out=dg_big[:, :N])
+    x = h_big[:, 64:].float().requires_grad_(True)
+    F.gelu(x).backward(a.float() @ w.float().t())
+    assert rel_err(dg_big[:, :N].float(), x.grad) < 4e-3
+    assert (dg_big[:, N:] == 3.0).all()
+    f32_big = torch.full((M, N + 8), -1.0, dtype=torch.float32, device="cuda")
+    ops.gemm_nt(ops.EPI_F32, a, w, bias, out=f32_big[:, 8:])
+    assert rel_err(f32_big[:, 8:], lin) < FP32_TOL and (f32_big[:, :8] == -1.0).all()
+
+
 @pytest.fixture(params=[1, 2], ids=["tile128", "pingpong256"])
 def tn_variant(request, ops):
     ops._L().mmae_gemm_tn_set_variant(request.param)

@@ -476,6 +476,27 @@ def test_checkpoint_round_trip_and_optimizer_interchange(tmp_path):
     assert set(exp["model"]) == {k for k in sd if not k.startswith("output_adapters.")}
 
 
+def test_bounded_run_ahead_keeps_results_and_event_count():
+    """max_steps_in_flight bounds the host's run-ahead with events of earlier steps: at most that many are pending, and
+    the step's results do not depend on the bound (0 = unbounded)."""
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    from multimae_amd.train import PretrainStep
+    cfg = O.small_cfg()
+    sd = G.perturbed_state(cfg, seed=7)
+    x = {d: t.cuda() for d, t in G.seeded_inputs(cfg, B=4, seed=3).items()}
+    rnd = O.draw_mask_randomness(4, [16, 16], 1.0, torch.Generator().manual_seed(2))
+    losses = {}
+    for bound in (0, 1, 2):
+        m = _build(cfg); m.load_state_dict(sd); m.cuda()
+        step = PretrainStep(m, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05, max_steps_in_flight=bound)
+        for _ in range(4):
+            loss, _, _ = step(x, mask_randomness=rnd)
+            assert len(step._step_events) <= max(bound, 0)
+        losses[bound] = loss.item()
+    assert losses[0] == losses[1] == losses[2]
+
+
 def test_reference_style_loop_with_utils_helpers():
     """The reference's loop shape (zero_grad, loss_scaler(loss, optimizer, clip_grad=..., parameters=...), per-iteration
     param_group["lr"]) over create_optimizer / NativeScalerWithGradNormCount equals PretrainStep."""
