@@ -72,32 +72,6 @@ __device__ __forceinline__ float add_bf16x8(float acc, const bf16x8& v) {
     return acc;
 }
 
-// erf-form GELU for GEMM epilogues.  erf(z) = sign(z) * (1 - P(t) * exp(-z^2)), t = 1 / (1 + p|z|)
-// (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7, far below the bf16 rounding of the result): one rcp, one exp and
-// six FMAs per element instead of the ~100-instruction branchy libm erff, which made the epilogue longer than the main loop.
-// `e` returns exp(-x^2/2) (= exp(-z^2) with z = x/sqrt(2)) for the derivative.
-__device__ __forceinline__ float erf_as(float z, float& e) {
-    const float az = fabsf(z);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);
-    e = __builtin_amdgcn_exp2f(-1.4426950408889634f * az * az);
-    float p = 1.061405429f;
-    p = p * t - 1.453152027f;
-    p = p * t + 1.421413741f;
-    p = p * t - 0.284496736f;
-    p = p * t + 0.254829592f;
-    const float r = 1.0f - p * t * e;
-    return z < 0.f ? -r : r;
-}
-__device__ __forceinline__ float gelu_erf(float x) {
-    float e;
-    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f, e));
-}
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-    float e;
-    const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f, e));
-    return cdf + x * 0.39894228040143267794f * e;
-}
-
 // GELU and its derivative on the packed fp32 ALU, without transcendentals.  Both Phi(x) - 1/2 and gelu'(x) - 1/2 are odd
 // functions: x * P(u) with u = x^2 scaled to [-1, 1] (least squares on Chebyshev nodes, scripts/fit_gelu_poly.py), fitted
 // under the condition that the value at the end of the range is exactly 1/2: the argument is clamped to the range and the
