@@ -47,8 +47,8 @@ CONFIGS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="vitb_rgbd")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
