@@ -1,5 +1,6 @@
 #!/bin/bash
 # In-step effect of the library's tuning switches: one bench run per setting, same box.
+# usage: sweep_env.sh "VAR=a" "VAR=b" ...   (the default configuration is run first and last)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/sweep
@@ -10,11 +11,5 @@ run() {
   python3 -c "import json;d=json.load(open('$OUT/b.json'));print('$*', d['value'], d['ms_per_step'])"
 }
 run MMAE_NOP=1
-run MMAE_PP_FILL=0.2
-run MMAE_PP_FILL=0.5
-run MMAE_PP_FILL=0.75
-run MMAE_LN_FWD_ROWS=1
-run MMAE_LN_FWD_ROWS=4
-run MMAE_DEC_STREAMS=0
-run MMAE_EAGER_OPT=0
+for setting in "$@"; do run $setting; done
 run MMAE_NOP=2
