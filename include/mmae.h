@@ -56,13 +56,15 @@ int mmae_gemm_nt(int epi, const void* A, long lda, const void* W, long ldw, int 
 void mmae_gemm_nt_set_variant(int variant);
 /* The 256x256 kernel may cut the last row panels into 128-row half tiles so that a thin last round of tiles is shared by
  * twice as many CUs (default on); 0 switches that off.  Per calling thread; for tests and tuning. */
-void mmae_gemm_nt_set_half_tiles(int on);
+void mmae_gemm_nt_set_half_tiles(int on);  /* 0: none; 1: 128- or 64-row tail tiles by cost (default); 2: 128-row tail tiles only */
 /* For timing the two launches of the 256x256 path separately: the calling thread's next mmae_gemm_nt calls run
  * 1 = the full-tile launch only, 2 = the half-tile launch only, 0 = both (default); other kernels ignore it.
  * mmae_gemm_nt_last_full_rows: rows the full tiles covered in the calling thread's last call (M when there was no
  * half-tile launch). */
 void mmae_gemm_nt_set_phase(int phase);
 int mmae_gemm_nt_last_full_rows(void);
+/* rows per tile of the second launch of that call (128 or 64), 0 when there was none */
+int mmae_gemm_nt_last_tail_rows(void);
 /* Kernel used by the calling thread's last mmae_gemm_nt / patch-embed / un-patchify call (codes as above, never 0). */
 int mmae_gemm_nt_last_kernel(void);
 

@@ -19,6 +19,7 @@ SIGNATURES = {
     "mmae_gemm_nt_set_half_tiles": (None, [_i]),
     "mmae_gemm_nt_set_phase": (None, [_i]),
     "mmae_gemm_nt_last_full_rows": (_i, []),
+    "mmae_gemm_nt_last_tail_rows": (_i, []),
     "mmae_gemm_nt_last_kernel": (_i, []),
     "mmae_gemm_tn_last_kernel": (_i, []),
     "mmae_gemm_tn_set_phase": (None, [_i]),

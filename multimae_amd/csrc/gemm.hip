@@ -51,7 +51,8 @@ struct GemmNT {
 // the stores just issued included, before touching a loaded value again).
 // RALL: the whole residual block (64 registers) is fetched before the first store, for callers with registers to spare
 // (one tile per CU in flight: the epilogue is then bound by the latency of each row's round trip).
-template <int EPI, bool FULL = false, bool BREG = false, bool RALL = false>
+// NMI: fragment rows of the block (4 = 64 rows; 2 = the 32-row blocks of the 64-row tiles)
+template <int EPI, bool FULL = false, bool BREG = false, bool RALL = false, int NMI = 4>
 __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&acc)[4][4], int mw, int nw, int fr, int fq,
                                                 const float* bias_regs = nullptr, const bf16x8 (*h_regs)[2] = nullptr) {
     // Epilogue inputs (saved pre-activation) are fetched for the whole 64x64 block before anything is stored:
@@ -94,14 +95,17 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
     }
     if (EPI == EPI_RESID) {
         load_res(0);
-        if (RALL) { load_res(1); load_res(2); load_res(3); }
+        if (RALL) {
+#pragma unroll
+            for (int q = 1; q < NMI; ++q) load_res(q);
+        }
     }
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        if (EPI == EPI_RESID && !RALL && mi + 1 < 4) load_res(mi + 1);
+    for (int mi = 0; mi < NMI; ++mi) {
+        if (EPI == EPI_RESID && !RALL && mi + 1 < NMI) load_res(mi + 1);
         if (EPI == EPI_DGELU && !h_regs && mi % MB == 0) {
 #pragma unroll
-            for (int mj = 0; mj < MB; ++mj) {
+            for (int mj = 0; mj < (MB < NMI ? MB : NMI); ++mj) {
                 int m = mw + (mi + mj) * 16 + fr;
                 m = m < p.M ? m : p.M - 1;
 #pragma unroll
@@ -225,7 +229,7 @@ __device__ __forceinline__ void store_wave_tile(const GemmNT& p, const f32x4 (&a
 //   EPI_DGELU: h_rows[mi][j] holds the saved pre-activations in the ROW layout (fetched by the caller ahead of the stores);
 //              they pass through the same piece to reach the accumulator layout
 //   EPI_RESID: the residual is fetched and added in the row layout, RES_AHEAD pieces ahead of the stores
-template <int EPI>
+template <int EPI, int NMI = 4>
 __device__ __forceinline__ void store_wave_tile_rows(const GemmNT& p, const f32x4 (&acc)[4][4], int mw, int nw, int lane,
                                                      char* stage, const float* bias_regs, const bf16x8 (*h_rows)[2] = nullptr) {
     static_assert(EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_RESID || EPI == EPI_DGELU || EPI == EPI_F32, "row-major epilogues");
@@ -243,7 +247,7 @@ __device__ __forceinline__ void store_wave_tile_rows(const GemmNT& p, const f32x
         char* const w0 = wrow + ((fq ^ wsw) << 4);
         char* const w1 = wrow + (((4 + fq) ^ wsw) << 4);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+        for (int mi = 0; mi < NMI; ++mi) {
             bf16x8 hacc[2];
             if constexpr (EPI == EPI_DGELU) {
                 *(bf16x8*)rd0 = h_rows[mi][0];
@@ -316,10 +320,10 @@ __device__ __forceinline__ void store_wave_tile_rows(const GemmNT& p, const f32x
             for (int q = 0; q < RES_AHEAD; ++q) load_res(q);
         }
 #pragma unroll
-        for (int piece = 0; piece < 8; ++piece) {
+        for (int piece = 0; piece < 2 * NMI; ++piece) {
             const int mi = piece >> 1, u = piece & 1;
             if constexpr (EPI == EPI_RESID) {
-                if (piece + RES_AHEAD < 8) load_res(piece + RES_AHEAD);
+                if (piece + RES_AHEAD < 2 * NMI) load_res(piece + RES_AHEAD);
             }
             f32x4 v0 = acc[2 * u][mi], v1 = acc[2 * u + 1][mi];
 #pragma unroll
@@ -617,8 +621,11 @@ extern "C" int mmae_debug_pp_trace(void* host_out) {
 #else
 #define PP_TRACE(slot) do {} while (0)
 #endif
-template <int EPI, bool HALF>
+template <int EPI, int TM>
 __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_m, int tiles_n) {
+    constexpr bool HALF = TM < 256;      // 128- and 64-row tiles: two phases per k-tile, one accumulator block per wave
+    constexpr bool QUARTER = TM == 64;   // 64-row tiles: the wave's block is 32 x 64 (two activation fragments)
+    constexpr int NMI = QUARTER ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) char ppsmem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -635,7 +642,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
     auto tile_origin = [&](int t, int& m0, int& n0) {
         if (HALF) {  // column tiles fastest: neighbouring workgroups share the 128 activation rows
             const int hp = t / tiles_n;
-            m0 = hp * 128;
+            m0 = hp * TM;
             n0 = (t - hp * tiles_n) * 256;
             return;
         }
@@ -663,7 +670,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
         for (int j = 0; j < 2; ++j) {
             const int r = (j * 8 + wave) * 8 + (ln >> 3);
             if (s == 0 || s == 3) {
-                int g = m0 + (HALF ? r : (r >> 6) * 128 + (s == 3 ? 64 : 0) + (r & 63));
+                // 64-row tiles: the second copy instruction of the slot fetches the same 64 rows again (into image rows that
+                // are never read), so that every slot stays two instructions and the counted waits hold for every tile size
+                int g = m0 + (QUARTER ? (r & 63) : HALF ? r : (r >> 6) * 128 + (s == 3 ? 64 : 0) + (r & 63));
                 g = g < p.M ? g : p.M - 1;
                 src[s][j] = p.A + (long)g * p.lda + (((ln & 7) ^ ((r >> 1) & 7)) << 3);
             } else {
@@ -721,13 +730,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
             for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     bf16x8 af[4][2], wlo[2][2], whi[2][2];
-    const int a_off = (wm * 64 + fr) * 128;                                 // + mi * 2048
+    const int a_off = (wm * (QUARTER ? 32 : 64) + fr) * 128;                // + mi * 2048
     const int w_off = (wn * 32 + 8 * (fr >> 2) + (fr & 3)) * 128;           // + t * 512
     const int ch0 = ((fq ^ swz) << 4), ch1 = (((4 + fq) ^ swz) << 4);
 
     auto read_a = [&](const char* slot) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+        for (int mi = 0; mi < NMI; ++mi) {
             af[mi][0] = *(const bf16x8*)(slot + a_off + mi * 2048 + ch0);
             af[mi][1] = *(const bf16x8*)(slot + a_off + mi * 2048 + ch1);
         }
@@ -746,7 +755,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < NMI; ++mi)
                     c[nbase + t][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[t][ks], af[mi][ks], c[nbase + t][mi], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
@@ -870,8 +879,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { bv[8 * u + e] = b0[e]; bv[8 * u + 4 + e] = b1[e]; }
             }
-            const bool full = m0 + (HALF ? 128 : 256) <= p.M && n0 + 256 <= p.N;  // workgroup-uniform
-            const int rb = m0 + wm * (HALF ? 64 : 128);                            // first row of this wave's block
+            const bool full = m0 + TM <= p.M && n0 + 256 <= p.N;  // workgroup-uniform
+            const int rb = m0 + wm * (TM / 2);                    // first row of this wave's block
             constexpr int NH2 = HALF ? 1 : 2;
 #ifdef MMAE_PP_ACC_EPILOGUE  // timing builds: stores straight from the accumulator layout
             constexpr bool ROWS = false;
@@ -889,25 +898,25 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
 #pragma unroll
                         for (int h2 = 0; h2 < NH2; ++h2)
 #pragma unroll
-                            for (int mi = 0; mi < 4; ++mi)
+                            for (int mi = 0; mi < NMI; ++mi)
 #pragma unroll
                                 for (int j = 0; j < 2; ++j)
                                     hs[h2][mi][j] = *(const bf16x8*)(hp + (long)(h2 * 64 + mi * 16 + 8 * j) * p.ldaux);
-                        store_wave_tile_rows<EPI>(p, acc[0], rb, n0 + wn * 64, lane, stage, bv, hs[0]);
+                        store_wave_tile_rows<EPI, NMI>(p, acc[0], rb, n0 + wn * 64, lane, stage, bv, hs[0]);
                         if (!HALF) store_wave_tile_rows<EPI>(p, acc[NH2 - 1], rb + 64, n0 + wn * 64, lane, stage, bv, hs[NH2 - 1]);
                     } else {
-                        store_wave_tile_rows<EPI>(p, acc[0], rb, n0 + wn * 64, lane, stage, bv);
+                        store_wave_tile_rows<EPI, NMI>(p, acc[0], rb, n0 + wn * 64, lane, stage, bv);
                         if (!HALF) store_wave_tile_rows<EPI>(p, acc[NH2 - 1], rb + 64, n0 + wn * 64, lane, stage, bv);
                     }
                 } else {
-                    store_wave_tile<EPI, false, !(EPI == EPI_DGELU)>(p, acc[0], rb, n0 + wn * 64, fr, fq, bv);
+                    store_wave_tile<EPI, false, !(EPI == EPI_DGELU), false, NMI>(p, acc[0], rb, n0 + wn * 64, fr, fq, bv);
                     if (!HALF) store_wave_tile<EPI, false, !(EPI == EPI_DGELU)>(p, acc[NH2 - 1], rb + 64, n0 + wn * 64, fr, fq, bv);
                 }
             } else if (full) {
-                store_wave_tile<EPI, true, true, HALF>(p, acc[0], rb, n0 + wn * 64, fr, fq, bv);
+                store_wave_tile<EPI, true, true, HALF, NMI>(p, acc[0], rb, n0 + wn * 64, fr, fq, bv);
                 if (!HALF) store_wave_tile<EPI, true, true>(p, acc[NH2 - 1], rb + 64, n0 + wn * 64, fr, fq, bv);
             } else {
-                store_wave_tile<EPI, false, true>(p, acc[0], rb, n0 + wn * 64, fr, fq, bv);
+                store_wave_tile<EPI, false, true, false, NMI>(p, acc[0], rb, n0 + wn * 64, fr, fq, bv);
                 if (!HALF) store_wave_tile<EPI, false, true>(p, acc[NH2 - 1], rb + 64, n0 + wn * 64, fr, fq, bv);
             }
 #pragma unroll
@@ -933,7 +942,7 @@ template <int EPI>
 static int launch_nt_pp(const GemmNT& p, hipStream_t s);
 // For timing the two launches of the ping-pong path separately: 0 = both (default), 1 = the full-tile launch only,
 // 2 = the half-tile launch only.  g_nt_full_rows: rows covered by full tiles in this thread's last gemm_nt call.
-static thread_local int g_nt_phase = 0, g_nt_full_rows = 0;
+static thread_local int g_nt_phase = 0, g_nt_full_rows = 0, g_nt_tail_rows = 0;
 
 static int g_num_cus = 0;
 static int num_cus();
@@ -945,21 +954,35 @@ static int num_cus();
 // row panels go to half tiles when that lowers rounds: typically when the last round of full tiles would occupy at most
 // half of the CUs.
 #define PP_HALF_COST 0.75
-struct PpPlan { int full_panels, tiles_n, halves; double rounds; };
-static thread_local int g_pp_halves = 1;  // 0 switches the half tiles off (tuning)
+// A round of 64-row tiles (two activation fragments per wave for the same weight reads as a half tile): taken instead of
+// half tiles where it lets every remaining row panel run at once on CUs that a round of half tiles would leave idle
+// (N = 768 at M = 25344: 168 workgroups of 64 rows instead of 84 of 128).
+#define PP_QUARTER_COST 0.55
+struct PpPlan { int full_panels, tiles_n, halves, tail_rows; double rounds; };  // tail_rows: 128 or 64 rows per tail tile
+static int pp_tails_default() {  // env MMAE_PP_TAILS overrides the default of mmae_gemm_nt_set_half_tiles (same-box comparisons)
+    const char* e = getenv("MMAE_PP_TAILS");
+    return e ? atoi(e) : 1;
+}
+static thread_local int g_pp_halves = pp_tails_default();  // 0: no tail tiles; 1: half or quarter tiles by cost; 2: half tiles only
 static PpPlan pp_plan(int M, int N, int K) {
     const int G = num_cus();
     const int tm = (M + 255) / 256, tn = (N + 255) / 256;
     const int total = tm * tn;
-    PpPlan pl = {tm, tn, 0, (double)((total + G - 1) / G)};
+    PpPlan pl = {tm, tn, 0, 128, (double)((total + G - 1) / G)};
     const int rem = total % G;  // full tiles of the last round (0: that round is full)
     if (!g_pp_halves || rem == 0 || K < 512) return pl;
     int cut = (rem + tn - 1) / tn;  // row panels to cut: the full tiles then end at or before a round boundary
     if (cut > tm) cut = tm;
     const int full_panels = tm - cut;
     const int halves = ((M - full_panels * 256 + 127) / 128) * tn;
-    const double r = (double)((full_panels * tn + G - 1) / G) + PP_HALF_COST * (double)((halves + G - 1) / G);
-    if (r < pl.rounds) { pl.full_panels = full_panels; pl.halves = halves; pl.rounds = r; }
+    const double base = (double)((full_panels * tn + G - 1) / G);
+    const double r = base + PP_HALF_COST * (double)((halves + G - 1) / G);
+    if (r < pl.rounds) { pl.full_panels = full_panels; pl.halves = halves; pl.tail_rows = 128; pl.rounds = r; }
+    if (g_pp_halves == 1) {
+        const int quarters = ((M - full_panels * 256 + 63) / 64) * tn;
+        const double rq = base + PP_QUARTER_COST * (double)((quarters + G - 1) / G);
+        if (rq < pl.rounds) { pl.full_panels = full_panels; pl.halves = quarters; pl.tail_rows = 64; pl.rounds = rq; }
+    }
     return pl;
 }
 static int num_cus() {
@@ -998,9 +1021,11 @@ template <int EPI>
 static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
     static bool reserved = false;
     if (!reserved) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+            e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e != hipSuccess) {
             mmae_set_error("gemm_nt: cannot reserve %d bytes of LDS: %s", PP_LDS, hipGetErrorString(e));
             return MMAE_ELAUNCH;
@@ -1009,14 +1034,15 @@ static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
     }
     // the row-mapped epilogues address output rows through tables of the whole problem: no second launch on a row offset
     PpPlan pl = pp_plan(p.M, p.N, p.K);
-    if (EPI == EPI_TOKENS || EPI == EPI_UNPATCH) pl = {(p.M + 255) / 256, (p.N + 255) / 256, 0, 0.0};
+    if (EPI == EPI_TOKENS || EPI == EPI_UNPATCH) pl = {(p.M + 255) / 256, (p.N + 255) / 256, 0, 128, 0.0};
     g_nt_full_rows = pl.halves ? pl.full_panels * 256 : p.M;
+    g_nt_tail_rows = pl.halves ? pl.tail_rows : 0;
     if (pl.full_panels > 0 && g_nt_phase != 2) {
         GemmNT q = p;
         if (pl.halves) q.M = pl.full_panels * 256;
         int grid = pl.full_panels * pl.tiles_n;
         if (grid > num_cus()) grid = num_cus();
-        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, false>), dim3(grid), dim3(512), PP_LDS, s, q, pl.full_panels, pl.tiles_n);
+        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, 256>), dim3(grid), dim3(512), PP_LDS, s, q, pl.full_panels, pl.tiles_n);
         MMAE_CHECK_LAUNCH("gemm_nt_pp");
     }
     if (pl.halves && g_nt_phase != 1) {
@@ -1032,7 +1058,10 @@ static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
         if (p.aux) q.aux = (const char*)p.aux + r0 * p.ldaux * aux_sz;
         int grid = pl.halves;
         if (grid > num_cus()) grid = num_cus();
-        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true>), dim3(grid), dim3(512), PP_LDS, s, q, (q.M + 127) / 128, pl.tiles_n);
+        if (pl.tail_rows == 64)
+            hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, 64>), dim3(grid), dim3(512), PP_LDS, s, q, (q.M + 63) / 64, pl.tiles_n);
+        else
+            hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, 128>), dim3(grid), dim3(512), PP_LDS, s, q, (q.M + 127) / 128, pl.tiles_n);
         MMAE_CHECK_LAUNCH("gemm_nt_pp(half tiles)");
     }
     return MMAE_OK;
@@ -1330,6 +1359,7 @@ extern "C" void mmae_gemm_nt_set_variant(int v) { g_nt_variant = v; }
 extern "C" void mmae_gemm_nt_set_half_tiles(int on) { g_pp_halves = on; }
 extern "C" void mmae_gemm_nt_set_phase(int phase) { g_nt_phase = phase; }
 extern "C" int mmae_gemm_nt_last_full_rows(void) { return g_nt_full_rows; }
+extern "C" int mmae_gemm_nt_last_tail_rows(void) { return g_nt_tail_rows; }
 
 template <int EPI>
 static int launch_nt(const GemmNT& p, hipStream_t s) {

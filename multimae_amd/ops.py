@@ -56,7 +56,7 @@ def _rows2d(t: torch.Tensor, name: str):
 PROFILE = None
 
 
-_NT_KERNELS = {1: "gemm_nt_kernel<%d>", 4: "gemm_nt_persist_kernel<%d, 2, 2>", 5: "gemm_nt_pp_kernel<%d, false>",
+_NT_KERNELS = {1: "gemm_nt_kernel<%d>", 4: "gemm_nt_persist_kernel<%d, 2, 2>", 5: "gemm_nt_pp_kernel<%d, 256>",
                7: "gemm_nt_p2_kernel<%d>"}
 _TN_KERNELS = {1: "gemm_tn_kernel", 2: "gemm_tn_pp_kernel"}
 
@@ -141,7 +141,7 @@ def gemm_nt(epi: int, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Ten
                 _lib.check(L.mmae_gemm_nt(*args, _stream()), "gemm_nt")
             if full() < M:
                 L.mmae_gemm_nt_set_phase(2)
-                with _Timed("gemm_nt", 2.0 * (M - full()) * N * K, "gemm_nt_pp_kernel<%d, true>" % epi):
+                with _Timed("gemm_nt", 2.0 * (M - full()) * N * K, lambda: "gemm_nt_pp_kernel<%d, %d>" % (epi, L.mmae_gemm_nt_last_tail_rows())):
                     _lib.check(L.mmae_gemm_nt(*args, _stream()), "gemm_nt")
         finally:
             L.mmae_gemm_nt_set_phase(0)

@@ -66,8 +66,13 @@ if __name__ == "__main__":
             bias = torch.randn(n, device="cuda")
             aux = r(m, n, dt=torch.float32) if epi == 2 else (r(m, n) if epi == 3 else None)
             ops._L().mmae_gemm_nt_set_variant(5)
-            t = timeit(lambda: ops.gemm_nt(epi, a, w, None if epi == 3 else bias, aux=aux), iters=30)
-            print(f"pp256 {name:12s} M={m} N={n} K={k}: {t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
+            res = []
+            for tails in (0, 2, 1):  # no tail tiles, 128-row tail tiles, 128- or 64-row by cost
+                ops._L().mmae_gemm_nt_set_half_tiles(tails)
+                t = timeit(lambda: ops.gemm_nt(epi, a, w, None if epi == 3 else bias, aux=aux), iters=30)
+                res.append(f"{t*1e6:8.1f} us {2*m*n*k/t/1e12:7.1f} TF")
+            ops._L().mmae_gemm_nt_set_half_tiles(1)
+            print(f"pp256 {name:12s} M={m} N={n} K={k}: full tiles only {res[0]} | 128-row tail {res[1]} | by cost {res[2]} (tail rows {ops._L().mmae_gemm_nt_last_tail_rows()})")
         sys.exit(0)
     for name, m, n, k, epi in shapes_nt:
         a, w = r(m, k), r(n, k)

@@ -27,10 +27,11 @@ def _randn(*shape, seed=0, dtype=torch.bfloat16, scale=1.0):
 
 
 # ---------------------------------------------------------------------------------------------- GEMM
-@pytest.fixture(params=[1, 4, 5, 6, 7], ids=["tile128", "persist128", "pingpong256", "pingpong256_full_tiles_only", "two_wg_128x256"])
+@pytest.fixture(params=[1, 4, 5, 6, 8, 7], ids=["tile128", "persist128", "pingpong256", "pingpong256_full_tiles_only", "pingpong256_half_tiles_only",
+                                              "two_wg_128x256"])
 def nt_variant(request, ops):
-    ops._L().mmae_gemm_nt_set_variant(5 if request.param == 6 else request.param)
-    ops._L().mmae_gemm_nt_set_half_tiles(0 if request.param == 6 else 1)
+    ops._L().mmae_gemm_nt_set_variant(5 if request.param in (6, 8) else request.param)
+    ops._L().mmae_gemm_nt_set_half_tiles({6: 0, 8: 2}.get(request.param, 1))  # default: 128- or 64-row tail tiles by cost
     yield request.param
     ops._L().mmae_gemm_nt_set_variant(0)
     ops._L().mmae_gemm_nt_set_half_tiles(1)
