@@ -366,17 +366,50 @@ class BlockFn(torch.autograd.Function):
 # the same pieces as stand-alone modules (no LayerNorm / residual around them): Mlp, Attention, CrossAttention
 # called directly, as the reference's classes can be (multimae/multimae_utils.py:162-169, :191-207, :224-247)
 # ---------------------------------------------------------------------------------------------
+def _rows_bf16(x: torch.Tensor) -> torch.Tensor:
+    """x [..., D] as contiguous bf16 rows [M, D]: cast from f32, taken as it is when already bf16 (LayerNormFn's output)."""
+    x2 = x.contiguous().reshape(-1, x.shape[-1])
+    return x2 if x2.dtype == torch.bfloat16 else ops.cast_bf16(x2)
+
+
+def _grad_epi(x: torch.Tensor) -> int:
+    """Epilogue of the product that forms the gradient of input x: the gradient has the input's dtype."""
+    return ops.EPI_BF16 if x.dtype == torch.bfloat16 else ops.EPI_F32
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension as a node of its own: x f32 [..., D] -> bf16 [..., D] (the operand type of the
+    product that follows it; MlpFn / AttentionFn / CrossAttentionFn take it without a cast and hand a bf16 gradient back).
+    The fused blocks carry their LayerNorms inside; this node serves the unfused paths (drop rates > 0 in training mode,
+    decoders without cross-attention or with their own queries)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x2 = x.contiguous().reshape(-1, x.shape[-1])
+        y, mean, rstd = ops.layernorm_fwd(x2, w, b, eps)
+        ctx.saved = (x2, mean, rstd, (w, b), x.shape)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, mean, rstd, (w, b), shape = ctx.saved
+        ctx.saved = None
+        dx, dw, db = _ln_bwd(_bf16(g.contiguous().reshape(x2.shape)), x2, w, b, mean, rstd)
+        return dx.reshape(shape), dw, db, None
+
+
 class MlpFn(torch.autograd.Function):
     """fc2(gelu(fc1(x))), x f32 [..., D] -> f32 [..., D_out]."""
 
     @staticmethod
     def forward(ctx, x, fc1_w, fc1_b, fc2_w, fc2_b):
-        xb = ops.cast_bf16(x.contiguous().reshape(-1, x.shape[-1]))
+        xb = _rows_bf16(x)
         w1, w1t = bf16_weights(fc1_w)
         w2, w2t = bf16_weights(fc2_w)
         h, act = ops.gemm_nt(ops.EPI_GELU, xb, w1, fc1_b)
         y = ops.gemm_nt(ops.EPI_F32, act, w2, fc2_b)
         ctx.saved = (xb, h, act, w1t, w2t, (fc1_w, fc1_b, fc2_w, fc2_b), x.shape)
+        ctx.in_epi = _grad_epi(x)
         return y.reshape(*x.shape[:-1], fc2_w.shape[0])
 
     @staticmethod
@@ -386,7 +419,7 @@ class MlpFn(torch.autograd.Function):
         gb = _bf16(g.contiguous().reshape(-1, g.shape[-1]))
         dh = ops.gemm_nt(ops.EPI_DGELU, gb, w2t, None, aux=h)
         dw2, db2 = _lin_grads(gb, act, fc2_w, fc2_b)
-        dx = ops.gemm_nt(ops.EPI_F32, dh, w1t, None)
+        dx = ops.gemm_nt(ctx.in_epi, dh, w1t, None)
         dw1, db1 = _lin_grads(dh, xb, fc1_w, fc1_b)
         return dx.reshape(shape), dw1, db1, dw2, db2
 
@@ -398,13 +431,14 @@ class AttentionFn(torch.autograd.Function):
     def forward(ctx, x, heads, qkv_w, qkv_b, proj_w, proj_b):
         B, N, D = x.shape
         d = D // heads
-        xb = ops.cast_bf16(x.contiguous().reshape(B * N, D))
+        xb = _rows_bf16(x)
         wq, wqt = bf16_weights(qkv_w)
         wp, wpt = bf16_weights(proj_w)
         qkv = ops.gemm_nt(ops.EPI_BF16, xb, wq, qkv_b)
         o, lse = ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, heads, N, N, d, d ** -0.5)
         y = ops.gemm_nt(ops.EPI_F32, o, wp, proj_b)
         ctx.saved = (xb, qkv, o, lse, wqt, wpt, (qkv_w, qkv_b, proj_w, proj_b), (B, N, D, heads))
+        ctx.in_epi = _grad_epi(x)
         return y.reshape(B, N, D)
 
     @staticmethod
@@ -418,7 +452,7 @@ class AttentionFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, d_o, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
                      B, heads, N, N, d, d ** -0.5)
-        dx = ops.gemm_nt(ops.EPI_F32, dqkv, wqt, None)
+        dx = ops.gemm_nt(ctx.in_epi, dqkv, wqt, None)
         dwq, dbq = _lin_grads(dqkv, xb, qkv_w, qkv_b)
         return dx.reshape(B, N, D), None, dwq, dbq, dwp, dbp
 
@@ -431,8 +465,9 @@ class CrossAttentionFn(torch.autograd.Function):
         B, N, D = x.shape
         M = context.shape[1]
         d = D // heads
-        xb = ops.cast_bf16(x.contiguous().reshape(B * N, D))
-        cb = ops.cast_bf16(context.contiguous().reshape(B * M, D))
+        xb = _rows_bf16(x)
+        cb = _rows_bf16(context)
+        ctx.in_epi = (_grad_epi(x), _grad_epi(context))
         wq, wqt = bf16_weights(q_w)
         wkv, wkvt = bf16_weights(kv_w)
         wp, wpt = bf16_weights(proj_w)
@@ -454,8 +489,8 @@ class CrossAttentionFn(torch.autograd.Function):
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         ops.attn_bwd(q, kv[:, :D], kv[:, D:], o, d_o, lse, dq, dkv[:, :D], dkv[:, D:], B, heads, N, M, d, d ** -0.5)
-        dx = ops.gemm_nt(ops.EPI_F32, dq, wqt, None)
-        dctx = ops.gemm_nt(ops.EPI_F32, dkv, wkvt, None)
+        dx = ops.gemm_nt(ctx.in_epi[0], dq, wqt, None)
+        dctx = ops.gemm_nt(ctx.in_epi[1], dkv, wkvt, None)
         dwq, dbq = _lin_grads(dq, xb, q_w, q_b)
         dwkv, dbkv = _lin_grads(dkv, cb, kv_w, kv_b)
         return dx.reshape(B, N, D), dctx.reshape(B, M, D), None, dwq, dbq, dwkv, dbkv, dwp, dbp
@@ -468,6 +503,22 @@ def round_up(v: int, m: int) -> int:
     return (v + m - 1) // m * m
 
 
+def _token_table_grad(dx: torch.Tensor, keep32: torch.Tensor, k: int, total: int) -> torch.Tensor:
+    """Gradient of the per-token additive table [total, D] (position embeddings) from dx f32 [B, k+G, D]: entry p sums, over
+    the samples that kept token p, the row of dx at p's rank.  Gather form in a fixed order (no atomics), 32 samples at a
+    time: only models with learnable position embeddings come here."""
+    B, _, D = dx.shape
+    out = torch.zeros((total, D), dtype=torch.float32, device=dx.device)
+    ar = torch.arange(k, device=dx.device).unsqueeze(0)
+    for b0 in range(0, B, 32):
+        kb = keep32[b0:b0 + 32].long()
+        inv = torch.full((kb.shape[0], total), k, dtype=torch.int64, device=dx.device)
+        inv.scatter_(1, kb, ar.expand(kb.shape[0], k))
+        rows = torch.cat([dx[b0:b0 + 32, :k], dx.new_zeros(kb.shape[0], 1, D)], dim=1)
+        out += torch.gather(rows, 1, inv.unsqueeze(-1).expand(-1, -1, D)).sum(dim=0)
+    return out
+
+
 class EmbedFn(torch.autograd.Function):
     """Kept-token patch embedding: Conv2d(k=s=P) + pos-emb + gather(ids_keep) + global tokens
     (multimae/input_adapters.py:126-135, multimae/multimae.py:393-406 of the reference) -> x f32 [B, k+G, D].
@@ -475,15 +526,20 @@ class EmbedFn(torch.autograd.Function):
     A class-map domain (int64 input + class-embedding table; the SemSegInputAdapter named at
     run_pretraining_multimae.py:72-85) is embedded while its patches are packed.
 
-    apply(keep32, patches, grid, pos_tables, global_tokens, n, *inputs[n], *proj_weights[n], *proj_biases[n], *class_embs[n])
-    with class_embs[t] = None for image domains."""
+    apply(keep32, patches, grid, pos_tables, global_tokens, n, *inputs[n], *proj_weights[n], *proj_biases[n], *class_embs[n],
+          *learnable_pos[n])
+    with class_embs[t] = None for image domains and learnable_pos[t] = pos_tables[t] again where the position table takes a
+    gradient (learnable_pos_emb, or sincos_pos_emb=False; multimae/input_adapters.py:84-95), None elsewhere (the group
+    may be left out altogether)."""
 
     @staticmethod
     def forward(ctx, keep32, patches, grid, pos_tables, global_tokens, n_img, *tensors):
+        ctx.n_tensors = len(tensors)
         images = tensors[:n_img]
         weights = tensors[n_img:2 * n_img]
         biases = tensors[2 * n_img:3 * n_img]
         class_embs = tensors[3 * n_img:4 * n_img]
+        pos_learn = tensors[4 * n_img:5 * n_img] or (None,) * n_img
         nh, nw = grid
         B = images[0].shape[0]
         D = weights[0].shape[0]
@@ -500,21 +556,29 @@ class EmbedFn(torch.autograd.Function):
         for w, n in zip(weights, widths):
             wcat[:, off:off + n] = w.detach().reshape(D, n)
             off += n
-        tab = ops.build_token_table([p.contiguous() for p in pos_tables], [b_.detach() for b_ in biases], ntok, D)
+        tab = ops.build_token_table([p.detach().contiguous() for p in pos_tables], [b_.detach() for b_ in biases], ntok, D)
         x = torch.empty((B, k + G, D), dtype=torch.float32, device=a.device)
         if k > 0:
             ops.patch_embed_gemm(a, wcat, keep32, tab, k, k + G, x)
         ops.append_global(global_tokens.detach().contiguous(), x, k)
         class_maps = [im if ce is not None else None for im, ce in zip(images, class_embs)]
         ctx.saved = (a, widths, [w.shape for w in weights], k, n_img, keep32, class_maps, weights, patches, (nh, nw),
-                     [None if ce is None else tuple(ce.shape) for ce in class_embs], (global_tokens, biases, class_embs))
+                     [None if ce is None else tuple(ce.shape) for ce in class_embs], (global_tokens, biases, class_embs), pos_learn)
         return x
 
     @staticmethod
     def backward(ctx, dx):
-        a, widths, wshapes, k, n_img, keep32, class_maps, weights, patches, (nh, nw), ce_shapes, (global_tokens, biases, class_embs) = ctx.saved
+        (a, widths, wshapes, k, n_img, keep32, class_maps, weights, patches, (nh, nw), ce_shapes, (global_tokens, biases, class_embs),
+         pos_learn) = ctx.saved
         ctx.saved = None
-        d_global, rows = ops.embed_bwd_reduce(dx.contiguous(), k)
+        dx = dx.contiguous()
+        d_pos = [None] * n_img
+        if any(p is not None for p in pos_learn):
+            table = _token_table_grad(dx, keep32, k, n_img * nh * nw)  # [n_img * ntok, D]
+            for t, p in enumerate(pos_learn):
+                if p is not None:
+                    d_pos[t] = _deliver(p, table[t * nh * nw:(t + 1) * nh * nw].t().reshape(1, -1, nh, nw))
+        d_global, rows = ops.embed_bwd_reduce(dx, k)
         dwcat = ops.gemm_tn(rows, a)  # [D, ktot]: patch columns, then the one-hot(domain) columns = bias grads
         kpatch = sum(widths)
         dws, dbs, dces, off = [], [], [], 0
@@ -534,7 +598,7 @@ class EmbedFn(torch.autograd.Function):
         dws = [_deliver(w, d) for w, d in zip(weights, dws)]
         dbs = [_deliver(b_, d) for b_, d in zip(biases, dbs)]
         dces = [_deliver(ce, d) for ce, d in zip(class_embs, dces)]
-        return (None, None, None, None, d_global, None, *([None] * n_img), *dws, *dbs, *dces)
+        return (None, None, None, None, d_global, None, *([None] * n_img), *dws, *dbs, *dces, *d_pos)[:6 + ctx.n_tensors]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -603,6 +667,64 @@ class DecoderHeadFn(torch.autograd.Function):
         d_task = [None if e is None else _deliver(e, d) for d, e in zip(d_task, task_embs)]
         return (d_enc, None, None, None, None, d_mask, dwpc, dbpc, dqnw, dqnb, dcnw, dcnb, dwq, dbq, dwkv, dbkv, dwpr, dbpr,
                 dnw, dnb, df1w, df1b, df2w, df2b, *d_task)
+
+
+class ContextAssembleFn(torch.autograd.Function):
+    """The first half of the decoder head as a node of its own (multimae/output_adapters.py:341-346 of the reference, body
+    :230-314): proj_context, mask-token fill, un-shuffle, task / position embeddings -> (queries f32 [B,ntok,Dd], context
+    f32 [B,k+G,Dd]).  Serves the decoder variants DecoderHeadFn does not fuse: no cross-attention (use_xattn=False), and
+    queries that are not this task's slice of the context (use_task_queries=False, or a task that is not among the input
+    domains): those are mask_token + position embedding (+ the task's embedding when the adapter has one), :280-293.
+
+    meta = (k, G, T, ntok, q_start, own_queries, q_emb_index, enc_bf16 or None); q_emb_index = position of the query task's
+    embedding in task_embs (the same parameter then serves context and queries and receives one summed gradient), -1 = the
+    separate tensor q_emb (None when the adapter has no embedding for its task)."""
+
+    @staticmethod
+    def forward(ctx, enc, keep32, restore32, meta, pos_table, mask_token, pc_w, pc_b, q_emb, *task_embs):
+        k, G, T, ntok, q_start, own_queries, q_emb_index, enc_b = meta
+        B, seq, D = enc.shape
+        Dd = pc_w.shape[0]
+        if enc_b is None:
+            enc_b = ops.cast_bf16(enc.contiguous().reshape(B * seq, D))
+        wpc, wpct = bf16_weights(pc_w)
+        ctxt = ops.gemm_nt(ops.EPI_BF16, enc_b, wpc, pc_b).reshape(B, seq, Dd)
+        emb = ops.build_decoder_emb([None if e is None else e.detach().contiguous() for e in task_embs], pos_table.contiguous(), ntok, Dd)
+        queries, context = ops.decoder_assemble_fwd(ctxt, mask_token.detach().contiguous(), emb, keep32, restore32, k, G,
+                                                    0 if own_queries else q_start, ntok)
+        if own_queries:
+            row = mask_token.detach().reshape(1, Dd) + pos_table.detach().reshape(Dd, ntok).t()
+            qe = task_embs[q_emb_index] if q_emb_index >= 0 else q_emb
+            if qe is not None:
+                row = row + qe.detach().reshape(1, Dd)
+            queries = row.unsqueeze(0).expand(B, ntok, Dd).contiguous()
+        ctx.saved = (enc_b, wpct, keep32, restore32, meta[:7], (B, seq, D, Dd), (mask_token, task_embs, q_emb, pc_w, pc_b))
+        return queries, context
+
+    @staticmethod
+    def backward(ctx, d_queries, d_context):
+        enc_b, wpct, keep32, restore32, (k, G, T, ntok, q_start, own_queries, q_emb_index), (B, seq, D, Dd), \
+            (mask_token, task_embs, q_emb, pc_w, pc_b) = ctx.saved
+        ctx.saved = None
+        d_queries = d_queries.contiguous()
+        dq_in = torch.zeros_like(d_queries) if own_queries else d_queries
+        d_ctx, d_mask, d_task = ops.decoder_assemble_bwd(dq_in, d_context.contiguous(), keep32, restore32, k, G, T, ntok,
+                                                         0 if own_queries else q_start, ntok)
+        d_task = list(d_task)
+        d_qemb = None
+        if own_queries:  # every query row is the same parameter sum: its gradient is the sum over samples and positions
+            dsum = d_queries.sum(dim=0).sum(dim=0)
+            d_mask = d_mask + dsum.reshape(d_mask.shape)
+            if q_emb_index >= 0:
+                d_task[q_emb_index] = d_task[q_emb_index] + dsum.reshape(d_task[q_emb_index].shape)
+            elif q_emb is not None:
+                d_qemb = _deliver(q_emb, dsum.reshape(q_emb.shape))
+        d_ctx2 = d_ctx.reshape(B * seq, Dd)
+        d_enc = ops.gemm_nt(ops.EPI_F32, d_ctx2, wpct, None).reshape(B, seq, D)
+        dwpc, dbpc = _lin_grads(d_ctx2, enc_b, pc_w, pc_b)
+        d_mask = _deliver(mask_token, d_mask)
+        d_task = [None if e is None else _deliver(e, d) for d, e in zip(d_task, task_embs)]
+        return (d_enc, None, None, None, None, d_mask, dwpc, dbpc, d_qemb, *d_task)
 
 
 class OutProjFn(torch.autograd.Function):

@@ -30,8 +30,6 @@ class PatchedInputAdapter(nn.Module):
         self.num_patches = (self.image_size[0] // self.patch_size_full[0]) * (self.image_size[1] // self.patch_size_full[1])
         self.P_H = max(1, self.patch_size_full[0] // stride_level)
         self.P_W = max(1, self.patch_size_full[1] // stride_level)
-        if learnable_pos_emb:
-            raise NotImplementedError("learnable positional embeddings are not wired into the fused patch-embed kernel")
         if self.P_H != self.P_W:
             raise NotImplementedError("square patches only")
         if dim_tokens is not None:
@@ -41,10 +39,12 @@ class PatchedInputAdapter(nn.Module):
         self.dim_tokens = dim_tokens
         h = self.image_size[0] // (self.stride_level * self.P_H)
         w = self.image_size[1] // (self.stride_level * self.P_W)
+        # as the reference (multimae/input_adapters.py:84-95): the sin-cos table is trained only with learnable_pos_emb, a
+        # table that does not start from sin-cos always is
         if self.sincos_pos_emb:
-            self.pos_emb = nn.Parameter(build_2d_sincos_posemb(h, w, dim_tokens), requires_grad=False)
+            self.pos_emb = nn.Parameter(build_2d_sincos_posemb(h, w, dim_tokens), requires_grad=bool(self.learnable_pos_emb))
         else:
-            self.pos_emb = nn.Parameter(torch.zeros(1, dim_tokens, h, w), requires_grad=False)
+            self.pos_emb = nn.Parameter(torch.zeros(1, dim_tokens, h, w))
             trunc_normal_(self.pos_emb, std=0.02)
         self.proj = nn.Conv2d(self.num_channels, dim_tokens, kernel_size=(self.P_H, self.P_W), stride=(self.P_H, self.P_W))
 
@@ -64,13 +64,18 @@ class PatchedInputAdapter(nn.Module):
             return self.pos_emb
         return F.interpolate(self.pos_emb, size=(nh, nw), mode="bicubic", align_corners=False)
 
+    def learnable_pos_table(self, table: torch.Tensor):
+        """`table` (the result of pos_table) when it takes a gradient, else None: the last argument group of EmbedFn."""
+        return table if self.pos_emb.requires_grad and torch.is_grad_enabled() else None
+
     def forward(self, x):
         B, C, H, W = x.shape
         nh, nw = self.grid(H, W)
         keep = torch.arange(nh * nw, dtype=torch.int32, device=x.device).expand(B, -1).contiguous()
         empty_global = torch.zeros(1, 0, self.dim_tokens, device=x.device)
-        return Fn.EmbedFn.apply(keep, [self.P_H], (nh, nw), [self.pos_table(nh, nw)], empty_global, 1, x, self.proj.weight,
-                                self.proj.bias, None)
+        table = self.pos_table(nh, nw)
+        return Fn.EmbedFn.apply(keep, [self.P_H], (nh, nw), [table], empty_global, 1, x, self.proj.weight,
+                                self.proj.bias, None, self.learnable_pos_table(table))
 
     class_table = None  # image domains have no class-embedding table
 
@@ -104,9 +109,9 @@ class SemSegInputAdapter(nn.Module):
             self.num_classes += 1
         self.P_H = max(1, self.patch_size_full[0] // stride_level)
         self.P_W = max(1, self.patch_size_full[1] // stride_level)
-        if learnable_pos_emb or interpolate_class_emb or emb_padding_idx is not None or self.P_H != self.P_W:
+        if interpolate_class_emb or emb_padding_idx is not None or self.P_H != self.P_W:
             raise NotImplementedError("the fused class-map embedding implements interpolate_class_emb=False, no padding index, "
-                                      "fixed pos_emb, square patches")
+                                      "square patches")
         if dim_tokens is not None:
             self.init(dim_tokens=dim_tokens)
 
@@ -115,9 +120,9 @@ class SemSegInputAdapter(nn.Module):
         h = self.image_size[0] // (self.stride_level * self.P_H)
         w = self.image_size[1] // (self.stride_level * self.P_W)
         if self.sincos_pos_emb:
-            self.pos_emb = nn.Parameter(build_2d_sincos_posemb(h, w, dim_tokens), requires_grad=False)
+            self.pos_emb = nn.Parameter(build_2d_sincos_posemb(h, w, dim_tokens), requires_grad=bool(self.learnable_pos_emb))
         else:
-            self.pos_emb = nn.Parameter(torch.zeros(1, dim_tokens, h, w), requires_grad=False)
+            self.pos_emb = nn.Parameter(torch.zeros(1, dim_tokens, h, w))
             trunc_normal_(self.pos_emb, std=0.02)
         self.class_emb = nn.Embedding(num_embeddings=self.num_classes, embedding_dim=self.dim_class_emb)
         trunc_normal_(self.class_emb.weight, std=0.02)
@@ -142,10 +147,13 @@ class SemSegInputAdapter(nn.Module):
             return self.pos_emb
         return F.interpolate(self.pos_emb, size=(nh, nw), mode="bilinear", align_corners=False)
 
+    learnable_pos_table = PatchedInputAdapter.learnable_pos_table
+
     def forward(self, x):
         B, H, W = x.shape
         nh, nw = self.grid(H, W)
         keep = torch.arange(nh * nw, dtype=torch.int32, device=x.device).expand(B, -1).contiguous()
         empty_global = torch.zeros(1, 0, self.dim_tokens, device=x.device)
-        return Fn.EmbedFn.apply(keep, [self.P_H], (nh, nw), [self.pos_table(nh, nw)], empty_global, 1, x.to(torch.int64),
-                                self.proj.weight, self.proj.bias, self.class_emb.weight)
+        table = self.pos_table(nh, nw)
+        return Fn.EmbedFn.apply(keep, [self.P_H], (nh, nw), [table], empty_global, 1, x.to(torch.int64),
+                                self.proj.weight, self.proj.bias, self.class_emb.weight, self.learnable_pos_table(table))

@@ -48,11 +48,10 @@ class MultiMAE(nn.Module):
         self.global_tokens = nn.Parameter(torch.zeros(1, num_global_tokens, dim_tokens))
         trunc_normal_(self.global_tokens, std=0.02)
 
-        if drop_path_rate:
-            raise NotImplementedError("drop_path_rate > 0 is not implemented in the fused blocks")
+        dpr = [r.item() for r in torch.linspace(0, drop_path_rate, depth)]  # stochastic depth decay rule (reference: multimae/multimae.py:98-110)
         self.encoder = nn.Sequential(*[
             Block(dim=dim_tokens, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop=drop_rate,
-                  attn_drop=attn_drop_rate, drop_path=0.0, norm_layer=norm_layer) for _ in range(depth)])
+                  attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer) for i in range(depth)])
         self._reset_parameters()
         self._last_ids_i32 = None
         self._concentrations = {}  # (device, alphas) -> Dirichlet concentrations on the device
@@ -209,9 +208,11 @@ class MultiMAE(nn.Module):
             keep32, restore32 = ids_keep.to(torch.int32).contiguous(), ids_restore.to(torch.int32).contiguous()
         input_info["_ids_keep_i32"], input_info["_ids_restore_i32"] = keep32, restore32
 
-        tokens = Fn.EmbedFn.apply(keep32, [ad.P_H for ad in adapters], (nh, nw), [ad.pos_table(nh, nw) for ad in adapters],
+        tables = [ad.pos_table(nh, nw) for ad in adapters]
+        tokens = Fn.EmbedFn.apply(keep32, [ad.P_H for ad in adapters], (nh, nw), tables,
                                   self.global_tokens, len(domains), *[x[d] for d in domains], *[ad.proj.weight for ad in adapters],
-                                  *[ad.proj.bias for ad in adapters], *[ad.class_table for ad in adapters])
+                                  *[ad.proj.bias for ad in adapters], *[ad.class_table for ad in adapters],
+                                  *[ad.learnable_pos_table(t) for ad, t in zip(adapters, tables)])
         encoder_tokens = self.encoder(tokens)
         if self.output_adapters is None:
             return encoder_tokens, task_masks
@@ -270,9 +271,11 @@ class MultiViT(MultiMAE):
         specs = OrderedDict((d, torch.empty((B, nh * nw, 0), device=device)) for d in domains)
         input_info = self.generate_input_info(specs, image_size=(H, W))
         keep32 = torch.arange(nh * nw * len(domains), dtype=torch.int32, device=device).expand(B, -1).contiguous()
-        tokens = Fn.EmbedFn.apply(keep32, [ad.P_H for ad in adapters], (nh, nw), [ad.pos_table(nh, nw) for ad in adapters],
+        tables = [ad.pos_table(nh, nw) for ad in adapters]
+        tokens = Fn.EmbedFn.apply(keep32, [ad.P_H for ad in adapters], (nh, nw), tables,
                                   self.global_tokens, len(domains), *[x[d] for d in domains], *[ad.proj.weight for ad in adapters],
-                                  *[ad.proj.bias for ad in adapters], *[ad.class_table for ad in adapters])
+                                  *[ad.proj.bias for ad in adapters], *[ad.class_table for ad in adapters],
+                                  *[ad.learnable_pos_table(t) for ad, t in zip(adapters, tables)])
         return tokens, input_info
 
     def forward(self, x: Union[Dict[str, torch.Tensor], torch.Tensor], return_all_layers=False, **kwargs):

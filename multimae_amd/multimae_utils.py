@@ -3,6 +3,7 @@ reference); the arithmetic runs in the HIP kernels through multimae_amd.function
 import math
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import functional as Fn
@@ -39,22 +40,36 @@ def trunc_normal_(tensor, mean=0.0, std=1.0, a=-2.0, b=2.0):
     return tensor
 
 
-def _no_dropout(**rates):
-    for name, r in rates.items():
-        if r:
-            raise NotImplementedError(f"{name}={r}: the HIP path implements the pretraining configuration (all drop rates 0)")
+def _no_attn_drop(module: nn.Module):
+    """Dropout on the attention probabilities would have to act inside the attention kernel, which keeps them in
+    registers: not implemented for training (in eval mode every dropout is the identity, as in the reference)."""
+    if module.training and module.attn_drop:
+        raise NotImplementedError(f"attn_drop={module.attn_drop} in training mode: the attention kernel has no dropout on its probabilities")
+
+
+def drop_path(x, drop_prob: float = 0.0, training: bool = False):
+    """Stochastic depth per sample (reference: multimae/multimae_utils.py:111-128, same draw: one torch.rand of shape
+    [B, 1, ...] in x's dtype on x's device, binarised by floor(keep + u); survivors scaled by 1 / keep)."""
+    if not drop_prob or not training:
+        return x
+    keep = 1.0 - drop_prob
+    gate = keep + torch.rand((x.shape[0],) + (1,) * (x.ndim - 1), dtype=x.dtype, device=x.device)
+    gate.floor_()
+    return x.div(keep) * gate
 
 
 class DropPath(nn.Module):
-    """Kept for API parity; only drop_prob == 0 (identity) is implemented."""
+    """Drop paths (stochastic depth) per sample, applied to the residual branches of a block."""
 
     def __init__(self, drop_prob=None):
         super().__init__()
-        _no_dropout(drop_path=drop_prob)
         self.drop_prob = drop_prob
 
     def forward(self, x):
-        return x
+        return drop_path(x, self.drop_prob, self.training)
+
+    def extra_repr(self) -> str:
+        return "p={}".format(self.drop_prob)
 
 
 class Mlp(nn.Module):
@@ -63,14 +78,15 @@ class Mlp(nn.Module):
 
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
         super().__init__()
-        _no_dropout(drop=drop)
         if act_layer is not nn.GELU:
             raise NotImplementedError("only nn.GELU (erf form) is fused into the GEMM epilogue")
         self.fc1 = nn.Linear(in_features, hidden_features or in_features)
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.drop = drop  # on the output of fc2 only (reference: multimae/multimae_utils.py:162-169)
 
     def forward(self, x):
-        return Fn.MlpFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        y = Fn.MlpFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        return F.dropout(y, self.drop, True) if self.training and self.drop else y
 
 
 class Attention(nn.Module):
@@ -78,14 +94,16 @@ class Attention(nn.Module):
 
     def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0.0, proj_drop=0.0):
         super().__init__()
-        _no_dropout(attn_drop=attn_drop, proj_drop=proj_drop)
         self.num_heads = num_heads
         self.scale = (dim // num_heads) ** -0.5
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim)
+        self.attn_drop, self.proj_drop = attn_drop, proj_drop
 
     def forward(self, x):
-        return Fn.AttentionFn.apply(x, self.num_heads, self.qkv.weight, _bias_or_zeros(self.qkv), self.proj.weight, self.proj.bias)
+        _no_attn_drop(self)
+        y = Fn.AttentionFn.apply(x, self.num_heads, self.qkv.weight, _bias_or_zeros(self.qkv), self.proj.weight, self.proj.bias)
+        return F.dropout(y, self.proj_drop, True) if self.training and self.proj_drop else y
 
 
 class CrossAttention(nn.Module):
@@ -93,16 +111,18 @@ class CrossAttention(nn.Module):
 
     def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0.0, proj_drop=0.0):
         super().__init__()
-        _no_dropout(attn_drop=attn_drop, proj_drop=proj_drop)
         self.num_heads = num_heads
         self.scale = (dim // num_heads) ** -0.5
         self.q = nn.Linear(dim, dim, bias=qkv_bias)
         self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim)
+        self.attn_drop, self.proj_drop = attn_drop, proj_drop
 
     def forward(self, x, context):
-        return Fn.CrossAttentionFn.apply(x, context, self.num_heads, self.q.weight, _bias_or_zeros(self.q), self.kv.weight,
-                                         _bias_or_zeros(self.kv), self.proj.weight, self.proj.bias)
+        _no_attn_drop(self)
+        y = Fn.CrossAttentionFn.apply(x, context, self.num_heads, self.q.weight, _bias_or_zeros(self.q), self.kv.weight,
+                                      _bias_or_zeros(self.kv), self.proj.weight, self.proj.bias)
+        return F.dropout(y, self.proj_drop, True) if self.training and self.proj_drop else y
 
 
 def _bias_or_zeros(lin: nn.Linear):
@@ -113,16 +133,23 @@ def _bias_or_zeros(lin: nn.Linear):
     return lin._mmae_zero_bias
 
 
+def layer_norm(norm: nn.LayerNorm, x):
+    """norm(x) through the LayerNorm kernel as an autograd node of its own: f32 in, bf16 out (what Mlp / Attention /
+    CrossAttention take as their operand)."""
+    return Fn.LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)
+
+
 class Block(nn.Module):
-    """x + attn(norm1(x)); x + mlp(norm2(x))  (reference: multimae/multimae_utils.py:250-285), one fused autograd node."""
+    """x + attn(norm1(x)); x + mlp(norm2(x))  (reference: multimae/multimae_utils.py:250-285): one fused autograd node;
+    with a drop rate > 0 in training mode the same kernels as separate nodes with the dropout / stochastic depth of the
+    reference between them."""
 
     def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, drop=0.0, attn_drop=0.0, drop_path=0.0,
                  act_layer=nn.GELU, norm_layer=nn.LayerNorm):
         super().__init__()
-        _no_dropout(drop_path=drop_path)
         self.norm1 = norm_layer(dim)
         self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
-        self.drop_path = nn.Identity()
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
         for n in (self.norm1, self.norm2):
@@ -131,6 +158,9 @@ class Block(nn.Module):
 
     def forward(self, x):
         a, m = self.attn, self.mlp
+        if self.training and (a.attn_drop or a.proj_drop or m.drop or isinstance(self.drop_path, DropPath)):
+            x = x + self.drop_path(a(layer_norm(self.norm1, x)))
+            return x + self.drop_path(m(layer_norm(self.norm2, x)))
         return Fn.BlockFn.apply(x, a.num_heads, self.norm1.weight, self.norm1.bias, a.qkv.weight, _bias_or_zeros(a.qkv),
                                 a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias,
                                 m.fc2.weight, m.fc2.bias)

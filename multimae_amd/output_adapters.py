@@ -9,7 +9,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from . import functional as Fn
-from .multimae_utils import Block, CrossAttention, Mlp, build_2d_sincos_posemb, pair, trunc_normal_
+from .multimae_utils import Block, CrossAttention, Mlp, build_2d_sincos_posemb, layer_norm, pair, trunc_normal_
 
 
 class SpatialOutputAdapter(nn.Module):
@@ -17,7 +17,14 @@ class SpatialOutputAdapter(nn.Module):
 
     proj_context -> (mask-token fill, un-shuffle, + task / position embeddings) -> queries = this task's slice
     -> cross-attention over the kept tokens (its output replaces the queries) -> MLP -> `depth` self-attention
-    blocks -> out_proj -> image.  Parameter names and shapes follow the reference so state_dicts interchange."""
+    blocks -> out_proj -> image.  Parameter names and shapes follow the reference so state_dicts interchange.
+
+    The pretraining configuration (task queries, cross-attention, no dropout) runs as one fused head node; the other
+    settings of the reference run the same kernels as separate nodes: use_xattn=False (the queries go straight to the
+    self-attention blocks, and the cross-attention / MLP modules do not exist, :135-148 and :349-355 there),
+    use_task_queries=False or a task that is not an input domain (queries = mask token + position embedding + the task's
+    embedding, :279-293), drop rates > 0 in training mode.  learnable_pos_emb=True is refused: the reference creates that
+    table as [1, h, w, D] (:129-131) and its own forward then fails in the position-embedding add."""
 
     def __init__(self, num_channels: int, stride_level: int, patch_size_full: Union[int, Tuple[int, int]],
                  dim_tokens_enc: Optional[int] = None, dim_tokens: int = 256, depth: int = 0, learnable_pos_emb: int = False,
@@ -39,8 +46,11 @@ class SpatialOutputAdapter(nn.Module):
         self.num_heads = num_heads
         self.P_H = max(1, self.patch_size_full[0] // stride_level)
         self.P_W = max(1, self.patch_size_full[1] // stride_level)
-        if not use_xattn or learnable_pos_emb or drop_path_rate or self.P_H != self.P_W:
-            raise NotImplementedError("the HIP decoder implements use_xattn=True, fixed sin-cos pos_emb, drop_path 0, square patches")
+        if learnable_pos_emb:
+            raise NotImplementedError("learnable_pos_emb=True: the reference builds this table as [1, h, w, D] and its own forward "
+                                      "fails on it; only the fixed sin-cos table is implemented")
+        if self.P_H != self.P_W:
+            raise NotImplementedError("square patches only")
 
         self.task_embeddings = None
         if context_tasks is not None:
@@ -52,16 +62,18 @@ class SpatialOutputAdapter(nn.Module):
         w = self.image_size[1] // (stride_level * self.P_W)
         self.pos_emb = nn.Parameter(build_2d_sincos_posemb(h, w, dim_tokens), requires_grad=False)
 
-        self.decoder = CrossAttention(dim=dim_tokens, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop_rate,
-                                      proj_drop=drop_rate)
-        self.context_norm = norm_layer(dim_tokens)
-        self.query_norm = norm_layer(dim_tokens)
-        self.out_norm = norm_layer(dim_tokens)
-        self.mlp = Mlp(in_features=dim_tokens, hidden_features=int(dim_tokens * mlp_ratio))
+        if use_xattn:
+            self.decoder = CrossAttention(dim=dim_tokens, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop_rate,
+                                          proj_drop=drop_rate)
+            self.context_norm = norm_layer(dim_tokens)
+            self.query_norm = norm_layer(dim_tokens)
+            self.out_norm = norm_layer(dim_tokens)
+            self.mlp = Mlp(in_features=dim_tokens, hidden_features=int(dim_tokens * mlp_ratio))
         if depth > 0:
+            dpr = [r.item() for r in torch.linspace(0, drop_path_rate, depth)]  # stochastic depth decay rule
             self.decoder_transformer = nn.Sequential(*[
                 Block(dim=dim_tokens, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop=drop_rate,
-                      attn_drop=attn_drop_rate, drop_path=0.0, norm_layer=norm_layer) for _ in range(depth)])
+                      attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer) for i in range(depth)])
         else:
             self.decoder_transformer = nn.Identity()
         self.dim_patch = num_channels * self.P_H * self.P_W
@@ -82,6 +94,23 @@ class SpatialOutputAdapter(nn.Module):
             return self.pos_emb
         return F.interpolate(self.pos_emb, size=(nh, nw), mode="bilinear", align_corners=False)
 
+    def _unfused_head(self, encoder_tokens, keep32, restore32, dims, enc_b, tasks, embs, nh, nw):
+        """Queries / context assembly, then (with use_xattn) cross-attention and MLP as separate autograd nodes."""
+        k, G, T, ntok, q_start, own_queries = dims
+        q_emb, q_emb_index = None, -1
+        if own_queries and self.task_embeddings is not None and self.task in self.task_embeddings:
+            if self.task in tasks:
+                q_emb_index = tasks.index(self.task)
+            else:
+                q_emb = self.task_embeddings[self.task]
+        meta = (k, G, T, ntok, q_start, own_queries, q_emb_index, enc_b)
+        queries, context = Fn.ContextAssembleFn.apply(encoder_tokens, keep32, restore32, meta, self._pos_table(nh, nw), self.mask_token,
+                                                      self.proj_context.weight, self.proj_context.bias, q_emb, *embs)
+        if not self.use_xattn:
+            return queries
+        x = self.decoder(layer_norm(self.query_norm, queries), layer_norm(self.context_norm, context))
+        return x + self.mlp(layer_norm(self.out_norm, x))
+
     def forward(self, encoder_tokens: Tensor, input_info: Dict, ids_keep: Tensor, ids_restore: Tensor, fp32_output: bool = False):
         assert self.dim_tokens_enc is not None, "Need to call init(dim_tokens_enc) function first"
         H, W = input_info["image_size"]
@@ -91,21 +120,25 @@ class SpatialOutputAdapter(nn.Module):
         G = input_info.get("num_global_tokens", 0)
         k = encoder_tokens.shape[1] - G
         ntok = nh * nw
-        if not self.use_task_queries or self.task not in input_info["tasks"]:
-            raise NotImplementedError("the HIP decoder implements the task-query path (task must be one of the input domains)")
         for t in tasks:
             if input_info["tasks"][t]["num_tokens"] != ntok:
                 raise NotImplementedError("all input domains must have the same token grid as this decoder")
-        q_start = input_info["tasks"][self.task]["start_idx"]
+        own_queries = not self.use_task_queries or self.task not in input_info["tasks"]
+        q_start = 0 if own_queries else input_info["tasks"][self.task]["start_idx"]
         keep32 = input_info.get("_ids_keep_i32")
         restore32 = input_info.get("_ids_restore_i32")
         if keep32 is None or restore32 is None:
             keep32, restore32 = ids_keep.to(torch.int32).contiguous(), ids_restore.to(torch.int32).contiguous()
         embs = [self.task_embeddings[t] if (self.task_embeddings is not None and t in self.task_embeddings) else None for t in tasks]
-        d, m = self.decoder, self.mlp
         enc_b = input_info.get("_enc_bf16")  # made once for all decoders by MultiMAE.forward
         if enc_b is not None and (enc_b.shape[0] != encoder_tokens.shape[0] * encoder_tokens.shape[1] or enc_b.device != encoder_tokens.device):
             enc_b = None
+        dropping = self.use_xattn and self.training and bool(self.decoder.attn_drop or self.decoder.proj_drop)
+        if own_queries or not self.use_xattn or dropping:
+            x = self._unfused_head(encoder_tokens, keep32, restore32, (k, G, len(tasks), ntok, q_start, own_queries), enc_b, tasks, embs, nh, nw)
+            x = self.decoder_transformer(x)
+            return Fn.OutProjFn.apply(x, self.out_proj.weight, self.out_proj.bias, self.num_channels, self.P_H, nh, nw, fp32_output)
+        d, m = self.decoder, self.mlp
         meta = (self.num_heads, k, G, len(tasks), ntok, q_start, enc_b)
         x = Fn.DecoderHeadFn.apply(
             encoder_tokens, keep32, restore32, meta, self._pos_table(nh, nw), self.mask_token,

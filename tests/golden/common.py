@@ -74,6 +74,61 @@ def perturbed_xattn_state(prefix, dim, seed):
     return _perturb(sd, seed + 1000)
 
 
+OPTION_GRAD_NAMES = [
+    "global_tokens",
+    "input_adapters.rgb.proj.bias",
+    "input_adapters.rgb.pos_emb",
+    "input_adapters.depth.pos_emb",
+    "encoder.0.attn.qkv.bias",
+    "encoder.0.attn.proj.bias",
+    "encoder.1.mlp.fc2.bias",
+    "encoder.1.norm1.weight",
+    "output_adapters.rgb.mask_token",
+    "output_adapters.depth.mask_token",
+    "output_adapters.rgb.task_embeddings.rgb",
+    "output_adapters.depth.task_embeddings.rgb",
+    "output_adapters.depth.task_embeddings.depth",
+    "output_adapters.rgb.proj_context.weight",
+    "output_adapters.depth.proj_context.bias",
+    "output_adapters.rgb.decoder.q.weight",
+    "output_adapters.depth.query_norm.weight",
+    "output_adapters.depth.mlp.fc1.weight",
+    "output_adapters.rgb.decoder_transformer.0.attn.proj.weight",
+    "output_adapters.depth.decoder_transformer.1.mlp.fc1.bias",
+    "output_adapters.rgb.out_proj.bias",  # (the L1 loss's bias gradient is a sum of signs: ill-conditioned under bf16 predictions)
+]
+
+
+OPTION_BATCH = 4
+
+
+def option_cases():
+    """The module settings outside the pretraining configuration, as variations of small_cfg: name -> (cfg, input-adapter
+    keyword arguments per domain, output-adapter keyword arguments, model keyword arguments, training mode)."""
+    two = {"rgb": (3, "rgb"), "depth": (1, "depth")}
+    base = dict(dim=128, depth=2, heads=4, dec_dim=64, dec_heads=2, patch=16, image=64)
+    rgbd = O.make_cfg({"rgb": 3, "depth": 1}, two, dec_depth=1, **base)
+    return {
+        "noxattn": (rgbd, {}, dict(use_xattn=False), {}, False),
+        "ownq": (rgbd, {}, dict(use_task_queries=False), {}, False),
+        "rgbonly": (O.make_cfg({"rgb": 3}, two, dec_depth=1, **base), {}, {}, {}, False),
+        "learnpos": (rgbd, {"rgb": dict(sincos_pos_emb=False), "depth": dict(learnable_pos_emb=True)}, {}, {}, False),
+        "droppath": (O.make_cfg({"rgb": 3, "depth": 1}, two, dec_depth=2, **base), {}, dict(drop_path_rate=0.3),
+                     dict(drop_path_rate=0.3), True),
+    }
+
+
+def option_state(cfg, seed, keys, random_tables=()):
+    """perturbed_state restricted to `keys` (the state_dict of the variant being built: a KeyError names a key the full
+    model does not have); the tables in `random_tables` are replaced by seeded N(0, 0.02) values."""
+    sd = perturbed_state(cfg, seed)
+    out = {k: sd[k] for k in keys}
+    g = torch.Generator().manual_seed(seed + 2000)
+    for k in random_tables:
+        out[k] = 0.02 * torch.randn(out[k].shape, generator=g)
+    return out
+
+
 def seeded_inputs(cfg, B, seed):
     g = torch.Generator().manual_seed(seed)
     S = cfg["image"]

@@ -280,6 +280,69 @@ def gen_multivit(fname="small_multivit.npz"):
     print(fname, "ok", tuple(last.shape))
 
 
+def gen_options(fname="options.npz"):
+    """The reference's module settings outside the pretraining configuration (no cross-attention, own queries, a decoder
+    whose task is not an input, learnable input position tables, stochastic depth in training mode): one step each."""
+    out = {}
+    for case, (cfg, ia_kw, oa_kw, m_kw, training) in G.option_cases().items():
+        S = cfg["image"]
+        ia = {d: ref.PatchedInputAdapter(num_channels=C, stride_level=1, patch_size_full=cfg["patch"], image_size=S,
+                                         **ia_kw.get(d, {})) for d, C in cfg["in_domains"].items()}
+        oa = {name: ref.SpatialOutputAdapter(num_channels=C, stride_level=1, patch_size_full=cfg["patch"],
+                                             dim_tokens=cfg["dec_dim"], depth=cfg["dec_depth"], num_heads=cfg["dec_heads"],
+                                             task=task, context_tasks=list(cfg["in_domains"]), image_size=S, **oa_kw)
+              for name, (C, task) in cfg["out_domains"].items()}
+        model = ref.MultiMAE(ia, oa, num_global_tokens=cfg["num_global"], dim_tokens=cfg["dim"], depth=cfg["depth"],
+                             num_heads=cfg["heads"], **m_kw)
+        tables = [f"input_adapters.{d}.pos_emb" for d, kw in ia_kw.items() if kw.get("sincos_pos_emb") is False]
+        model.load_state_dict(G.option_state(cfg, 7, list(model.state_dict().keys()), tables), strict=True)
+        model.train(training)
+        B, k, seed = G.OPTION_BATCH, 8, 5
+        x_all = G.seeded_inputs(O.small_cfg(), B=B, seed=3)
+        x = {d: x_all[d] for d in cfg["in_domains"]}
+        n = (S // cfg["patch"]) ** 2
+        p, noises, noise_all = replay_mask_rng(seed, B, [n] * len(x), 1.0, False)
+        G.assert_tie_free(p, noises, noise_all, k)
+        losses_fn = {"rgb": ref.MaskedMSELoss(patch_size=16, stride=1), "depth": ref.MaskedMSELoss(patch_size=16, stride=1)}  # (L1's sign gradients are ill-conditioned under bf16; tested elsewhere)
+        pre = case + "_"
+        out[pre + "p"], out[pre + "noise_all"] = p.numpy(), noise_all.numpy()
+        for i, nz in enumerate(noises):
+            out[pre + f"noise{i}"] = nz.numpy()
+        # stochastic depth draws (torch.rand of shape [B, 1, 1]) in call order
+        draws, real_rand = [], torch.rand
+
+        def logging_rand(*a, **kw):
+            r = real_rand(*a, **kw)
+            if tuple(r.shape) == (B, 1, 1):
+                draws.append(r.clone())
+            return r
+        torch.manual_seed(seed)
+        model.zero_grad()
+        torch.rand = logging_rand
+        try:
+            preds, masks = model(x, num_encoded_tokens=k, alphas=1.0)
+        finally:
+            torch.rand = real_rand
+        # targets of a domain that is not an input come from the full seeded set; its loss then runs without a mask
+        losses = {t: losses_fn[t](preds[t].float(), x_all[t], mask=masks.get(t)) for t in preds}
+        sum(losses.values()).backward()
+        named = dict(model.named_parameters())
+        for t in preds:
+            out[pre + f"pred_{t}"] = preds[t].detach().numpy().astype(np.float16)  # compared at 2e-2: half precision is ample
+            out[pre + f"loss_{t}"] = losses[t].detach().numpy()
+        for d in masks:
+            out[pre + f"mask_{d}"] = masks[d].numpy().astype(np.uint8)
+        for name in G.OPTION_GRAD_NAMES:
+            if name in named and named[name].grad is not None:
+                out[pre + "grad_" + name] = named[name].grad.numpy()
+        out[pre + "grad_norm"] = torch.sqrt(sum((q.grad.double() ** 2).sum() for q in named.values() if q.grad is not None)).numpy()
+        out[pre + "n_trainable"] = np.int64(sum(q.numel() for q in named.values() if q.requires_grad))
+        if draws:
+            out[pre + "droppath_draws"] = torch.stack(draws).numpy()
+        print(case, "ok; losses", {t: float(v) for t, v in losses.items()}, "draws", len(draws))
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+
+
 def gen_keys():
     """Digest of the reference's downstream-export key list (utils/multimae_keys.py:4-156) and its length."""
     from utils.multimae_keys import MULTIVIT_PRETRAINED_KEYS
@@ -398,6 +461,7 @@ if __name__ == "__main__":
     gen_semseg_e2e()
     gen_schedule()
     gen_multivit()
+    gen_options()
     gen_keys()
     gen_masks()
     gen_posemb()

@@ -1,0 +1,136 @@
+"""The module settings outside the pretraining configuration against the reference's golden outputs
+(tests/golden/options.npz, written by make_golden.py gen_options from the reference's own classes): decoders without
+cross-attention, decoders with their own queries, a decoder whose task is not an input, learnable input position tables,
+stochastic depth in training mode.  bf16 tolerance: 2e-2 relative (L2 over a tensor); masks bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+BF16_TOL = 2e-2
+
+
+def _build(case):
+    import multimae_amd as M
+    from tests.golden import common as G
+    cfg, ia_kw, oa_kw, m_kw, training = G.option_cases()[case]
+    S = cfg["image"]
+    ia = {d: M.PatchedInputAdapter(num_channels=C, stride_level=1, patch_size_full=cfg["patch"], image_size=S, **ia_kw.get(d, {}))
+          for d, C in cfg["in_domains"].items()}
+    oa = {name: M.SpatialOutputAdapter(num_channels=C, stride_level=1, patch_size_full=cfg["patch"], dim_tokens=cfg["dec_dim"],
+                                       depth=cfg["dec_depth"], num_heads=cfg["dec_heads"], task=task,
+                                       context_tasks=list(cfg["in_domains"]), image_size=S, **oa_kw)
+          for name, (C, task) in cfg["out_domains"].items()}
+    model = M.MultiMAE(ia, oa, num_global_tokens=cfg["num_global"], dim_tokens=cfg["dim"], depth=cfg["depth"],
+                       num_heads=cfg["heads"], **m_kw)
+    tables = [f"input_adapters.{d}.pos_emb" for d, kw in ia_kw.items() if kw.get("sincos_pos_emb") is False]
+    # strict: the variant has exactly the reference's state_dict keys (no cross-attention modules without use_xattn)
+    model.load_state_dict(G.option_state(cfg, 7, list(model.state_dict().keys()), tables), strict=True)
+    return model.cuda().train(training), cfg
+
+
+@pytest.mark.parametrize("case", ["noxattn", "ownq", "rgbonly", "learnpos", "droppath"])
+def test_module_option_vs_reference_golden(case, monkeypatch):
+    import multimae_amd as M
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    z = G.load("options.npz")
+    pre = case + "_"
+    model, cfg = _build(case)
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == int(z[pre + "n_trainable"])
+    x_all = {d: t.cuda() for d, t in G.seeded_inputs(O.small_cfg(), B=G.OPTION_BATCH, seed=3).items()}
+    x = {d: x_all[d] for d in cfg["in_domains"]}
+    rnd = (torch.from_numpy(z[pre + "p"]), [torch.from_numpy(z[pre + f"noise{i}"]) for i in range(len(x))],
+           torch.from_numpy(z[pre + "noise_all"]))
+    if pre + "droppath_draws" in z.files:  # replay the reference's stochastic-depth draws, in call order
+        draws, real_rand = list(torch.from_numpy(z[pre + "droppath_draws"])), torch.rand
+
+        def replayed_rand(*size, **kw):
+            shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+            if shape == (G.OPTION_BATCH, 1, 1):
+                return draws.pop(0).to(device=kw.get("device"), dtype=kw.get("dtype") or torch.float32)
+            return real_rand(*size, **kw)
+        monkeypatch.setattr(torch, "rand", replayed_rand)
+    losses_fn = {"rgb": M.MaskedMSELoss(patch_size=16, stride=1), "depth": M.MaskedMSELoss(patch_size=16, stride=1)}
+    preds, masks = model(x, num_encoded_tokens=8, alphas=1.0, mask_randomness=rnd)
+    losses = {t: losses_fn[t](preds[t], x_all[t], mask=masks.get(t)) for t in preds}
+    sum(losses.values()).backward()
+    if pre + "droppath_draws" in z.files:
+        assert not draws, f"{len(draws)} stochastic-depth draws of the reference were not consumed"
+    for d in masks:
+        assert np.array_equal(masks[d].cpu().numpy(), z[pre + f"mask_{d}"].astype(np.int64)), d
+    grads = {n: p.grad for n, p in model.named_parameters() if p.requires_grad}
+    report = {}
+    for t in preds:
+        report[f"pred_{t}"] = rel_err(preds[t].float().cpu(), z[pre + f"pred_{t}"].astype(np.float32))
+        report[f"loss_{t}"] = abs(losses[t].item() - float(z[pre + f"loss_{t}"])) / abs(float(z[pre + f"loss_{t}"]))
+    checked = 0
+    for key in z.files:
+        if key.startswith(pre + "grad_") and key != pre + "grad_norm":
+            name = key[len(pre) + 5:]
+            assert grads.get(name) is not None, f"no gradient for {name}"
+            report["grad_" + name] = rel_err(grads[name].cpu(), z[key])
+            checked += 1
+    assert checked >= 10
+    gn = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values() if g is not None)).item()
+    report["grad_norm"] = abs(gn - float(z[pre + "grad_norm"])) / float(z[pre + "grad_norm"])
+    print(case, {k_: f"{v:.2e}" for k_, v in report.items()})
+    bad = {k_: v for k_, v in report.items() if not v < BF16_TOL}
+    assert not bad, bad
+
+
+def test_dropout_settings_are_the_identity_in_eval_mode_and_drop_in_training_mode():
+    """drop_rate acts on the projections' outputs (the reference's proj_drop / Mlp.drop): eval mode equals the model
+    without dropout bitwise; training mode zeroes about drop_rate of a block's branch outputs; dropout on the attention
+    probabilities is refused in training mode only."""
+    import multimae_amd as M
+    torch.manual_seed(0)
+    blk0 = M.multimae_utils.Block(128, 4, qkv_bias=True, norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6)).cuda()
+    blk = M.multimae_utils.Block(128, 4, qkv_bias=True, drop=0.25, attn_drop=0.1, drop_path=0.2,
+                                 norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6)).cuda()
+    blk.load_state_dict(blk0.state_dict(), strict=True)
+    x = torch.randn(4, 40, 128, device="cuda")
+    assert torch.equal(blk.eval()(x), blk0.eval()(x))
+    with pytest.raises(NotImplementedError):
+        blk.train()(x)
+    blk.attn.attn_drop = 0.0
+    y = blk.train()(x.requires_grad_())
+    y.sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all() and blk.mlp.fc1.weight.grad is not None
+    mlp = M.multimae_utils.Mlp(128, 512, drop=0.25).cuda().train()
+    frac = (mlp(torch.randn(64, 40, 128, device="cuda")) == 0).float().mean().item()
+    assert 0.2 < frac < 0.3, frac
+
+
+def test_learnable_output_position_table_is_refused_as_in_the_reference():
+    import multimae_amd as M
+    with pytest.raises(NotImplementedError):
+        M.SpatialOutputAdapter(num_channels=3, stride_level=1, patch_size_full=16, learnable_pos_emb=True)
+
+
+def test_learnable_position_tables_in_flat_storage_take_the_same_gradient():
+    """With the parameters in flat storage (the step's layout) the position-table gradient is written in place by the
+    embedding's backward; it must equal the one autograd delivers for the plain module."""
+    import multimae_amd as M
+    from multimae_amd.train import FlatParams
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    z = G.load("options.npz")
+    x = {d: t.cuda() for d, t in G.seeded_inputs(O.small_cfg(), B=G.OPTION_BATCH, seed=3).items()}
+    rnd = (torch.from_numpy(z["learnpos_p"]), [torch.from_numpy(z[f"learnpos_noise{i}"]) for i in range(2)],
+           torch.from_numpy(z["learnpos_noise_all"]))
+    grads = []
+    for flat in (False, True):
+        model, _ = _build("learnpos")
+        holder = FlatParams(model) if flat else None
+        preds, masks = model(x, num_encoded_tokens=8, alphas=1.0, mask_randomness=rnd)
+        sum(M.MaskedMSELoss(patch_size=16, stride=1)(preds[t], x[t], mask=masks[t]) for t in preds).backward()
+        M.functional.join_side_stream()
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters() if p.requires_grad})
+        if flat:
+            assert all(p.grad.data_ptr() >= holder.grads.data_ptr() for p in model.parameters() if p.requires_grad)
+    for name in ("input_adapters.rgb.pos_emb", "input_adapters.depth.pos_emb", "global_tokens"):
+        assert grads[0][name].abs().sum() > 0
+        assert torch.equal(grads[0][name], grads[1][name]), name
