@@ -6,7 +6,6 @@ accumulates in fp32.  Each function saves exactly what its backward kernels read
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import os
-import weakref
 
 import torch
 
@@ -49,29 +48,24 @@ def clear_weight_cache():
 
 
 # bf16 shadow of the fp32 gradient that a LayerNorm backward just produced: the next consumer needs both precisions
-# (fp32 for the residual path, bf16 as a GEMM operand).  One entry at most; valid only while the producer tensor is alive
-# and the consumer's tensor is the same, unmodified memory.
-_SHADOW = None
-
-
+# (fp32 for the residual path, bf16 as a GEMM operand).  The shadow travels with the fp32 tensor itself, as an attribute
+# (a tensor keeps its Python object for as long as it lives, so the attribute survives the trip through the autograd
+# engine); a consumer that holds a whole-tensor view of it finds it through the view's base.  A gradient that the engine
+# summed with another, or that anything modified in place since, carries no (valid) shadow and is cast.
 def _set_shadow(dx: torch.Tensor, dxb: torch.Tensor):
-    global _SHADOW
-    _SHADOW = (weakref.ref(dx), dx.data_ptr(), dx.numel(), dxb, dx._version)
-
-
-def clear_shadow():
-    global _SHADOW
-    _SHADOW = None
+    dx._mmae_shadow = (dxb, dx._version)
 
 
 def _bf16(g: torch.Tensor) -> torch.Tensor:
-    global _SHADOW
     if g.dtype == torch.bfloat16:
         return g
-    ent, _SHADOW = _SHADOW, None
-    if (ent is not None and ent[0]() is not None and ent[1] == g.data_ptr() and ent[2] == g.numel() and g.is_contiguous()
-            and g._version == ent[4]):  # same memory, producer still alive, not accumulated into in place since
-        return ent[3].reshape(g.shape)
+    root = g._base if g._base is not None else g
+    ent = getattr(root, "_mmae_shadow", None)
+    if ent is not None:
+        root._mmae_shadow = None  # one consumer; the bf16 copy is not kept alive beyond it
+        if (ent[1] == g._version and g.is_contiguous() and g.numel() == root.numel()
+                and g.storage_offset() == root.storage_offset()):  # all of it, unmodified since the shadow was made
+            return ent[0].reshape(g.shape)
     return ops.cast_bf16(g.contiguous())
 
 
@@ -762,14 +756,20 @@ class MaskedCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (d_logits,) = ctx.saved_tensors
-        if UNIT_LOSS_GRADS:
+        if getattr(ctx, "unit_upstream", False):
             return d_logits, None, None, None, None
         return d_logits * g.to(d_logits.dtype), None, None, None, None
 
 
-# Set (by PretrainStep, around its backward call) while the gradient arriving at every loss is exactly 1: the losses
-# then hand out the gradient their forward kernel wrote instead of a scaled copy (an image-sized multiply per loss).
-UNIT_LOSS_GRADS = False
+def mark_unit_upstream(losses) -> None:
+    """Tell the graph nodes of these loss tensors (outputs of MaskedLossFn / MaskedCEFn) that the gradient arriving at them
+    will be exactly 1, as for the terms of a plain sum that backward() is called on: their backward then hands out the
+    gradient the forward kernel wrote instead of a scaled copy (an image-sized multiply per loss).  The mark sits on the
+    node of one forward call, so it ends with that graph; other tensors and other graphs are unaffected."""
+    for t in losses:
+        node = getattr(t, "grad_fn", None)
+        if isinstance(node, (MaskedLossFn._backward_cls, MaskedCEFn._backward_cls)):
+            node.unit_upstream = True
 
 
 class MaskedLossFn(torch.autograd.Function):
@@ -784,6 +784,6 @@ class MaskedLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (d_pred,) = ctx.saved_tensors
-        if UNIT_LOSS_GRADS:  # the caller vouches that g is exactly 1 (a plain sum of the task losses)
+        if getattr(ctx, "unit_upstream", False):  # the caller vouched that g is exactly 1 (mark_unit_upstream)
             return d_pred, None, None, None, None, None
         return d_pred * g.to(d_pred.dtype), None, None, None, None, None

@@ -532,14 +532,13 @@ class PretrainStep:
                                   sample_tasks_uniformly=self.uniform, fp32_output_adapters=self.fp32_out)
         task_losses = {t: fn(preds[t], batch[tgt], mask=masks.get(tgt)) for t, (fn, tgt) in self.losses.items()}
         loss = sum(task_losses.values())
-        Fn.UNIT_LOSS_GRADS = True  # d(loss) / d(task loss) = 1 for every task
+        Fn.mark_unit_upstream(task_losses.values())  # loss is their plain sum: d(loss) / d(task loss) = 1 for every task
         self.buckets.reset()        # completion signals left by a backward pass outside this step
         self._armed = True
         try:
             loss.backward()
             self.buckets.finish()
         finally:
-            Fn.UNIT_LOSS_GRADS = False
             self._armed = False
         Fn.join_side_stream()
         gn2 = self.opt.grad_norm_sq()  # of the summed (not yet averaged) gradients: norm = sqrt(gn2) / world
