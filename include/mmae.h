@@ -130,11 +130,26 @@ int mmae_layernorm_param_reduce(const void* workspace, size_t workspace_bytes, i
  * tile); accumulation in registers, no atomics; workspace holds rowsum(dO*O) [B,H,q_len] f32 for the two-kernel form. */
 int mmae_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
                   float* lse, int B, int H, int q_len, int kv_len, int head_dim, float scale, mmae_stream_t stream);
+/* Longest sequence one call takes at this head_dim (a multiple of 32; 0 for an unsupported head_dim): backward = 0: kv_len
+ * of mmae_attn_fwd (q_len is not limited there); backward = 1: q_len and kv_len of mmae_attn_bwd.  Longer sequences are
+ * served by the caller in chunks of keys (forward: partial outputs merged through their log-sum-exps) and of queries x
+ * keys (backward: partial gradients summed), as multimae_amd/ops.py does. */
+int mmae_attn_max_len(int head_dim, int backward);
 size_t mmae_attn_bwd_workspace_bytes(int B, int H, int q_len);
 int mmae_attn_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* o, long ldo,
                   const void* d_o, long lddo, const float* lse, void* dq, long lddq, void* dk, long lddk, void* dv,
                   long lddv, int B, int H, int q_len, int kv_len, int head_dim, float scale, void* workspace,
                   size_t workspace_bytes, mmae_stream_t stream);
+/* mmae_attn_bwd for one (chunk of queries, chunk of keys) of rows longer than one call takes: q / o / d_o / lse / dq are the
+ * chunk's queries with the log-sum-exp and output of their WHOLE rows, k / v / dk / dv the chunk's keys; dq is this key chunk's
+ * share (the caller sums the shares over the key chunks, and dk / dv over the query chunks).  mean_key [B,H,head_dim] f32: the
+ * mean over ALL keys of the row (the kernels take the rounding residue of dS's row sum out of dQ along the mean key; the
+ * residue only cancels over the whole row, so every chunk has to use the same vector); NULL = the mean of this call's keys,
+ * which makes the call mmae_attn_bwd. */
+int mmae_attn_bwd_chunk(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* o, long ldo,
+                        const void* d_o, long lddo, const float* lse, const float* mean_key, void* dq, long lddq, void* dk,
+                        long lddk, void* dv, long lddv, int B, int H, int q_len, int kv_len, int head_dim, float scale,
+                        void* workspace, size_t workspace_bytes, mmae_stream_t stream);
 /* Kernel choice for mmae_attn_bwd: 0 = by size (default), 1 = two kernels, 2 = one kernel whenever Q, dO, K, V of a head
  * fit the 160 KiB LDS.  Per calling thread; for tests and tuning. */
 void mmae_attn_bwd_set_variant(int variant);

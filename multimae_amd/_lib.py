@@ -36,9 +36,12 @@ SIGNATURES = {
     "mmae_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "mmae_layernorm_bwd_set_variant": (_i, [_i]),
     "mmae_attn_fwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "mmae_attn_max_len": (_i, [_i, _i]),
     "mmae_attn_bwd_workspace_bytes": (_z, [_i, _i, _i]),
     "mmae_attn_bwd_set_variant": (None, [_i]),
     "mmae_attn_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _p, _l, _p, _p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _i, _f, _p, _z, _p]),
+    "mmae_attn_bwd_chunk": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _p, _l, _p, _p, _p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _i, _f, _p, _z,
+                                 _p]),
     "mmae_mask_generate": (_i, [_p, _p, _p, C.POINTER(_i), _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "mmae_pack_patches": (_i, [C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_p), C.POINTER(_i), _i, _i, _i, _i, _p, _i,
                                 _p, _i, _p]),

@@ -25,6 +25,8 @@ struct AttnArgs {
     bf16* dk; long lddk;
     bf16* dv; long lddv;
     float* delta;  // [B,H,q_len] workspace: rowsum(dO * O), written by the dQ kernel, read by the dK/dV kernel
+    const float* mean_key;  // [B,H,D] or null: the vector dQ's residual row sum is taken out along, when the keys of this call
+                            // are only a chunk of the row (the mean over all of the row's keys; null: the mean of the call's keys)
     int B, H, q_len, kv_len;
     float scale;
 };
@@ -249,7 +251,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs p, int nk
     __syncthreads();
     if (tid < D) {
         float sum = 0.f;
-        for (int n = 0; n < p.kv_len; ++n) sum += (float)Ks[n * LDR + tid];
+        if (p.mean_key) {
+            sum = p.mean_key[((long)b * p.H + h) * D + tid] * (float)p.kv_len;
+        } else {
+            for (int n = 0; n < p.kv_len; ++n) sum += (float)Ks[n * LDR + tid];
+        }
         kbar[tid] = sum / (float)p.kv_len;
     }
     __syncthreads();
@@ -544,7 +550,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_bwd_fused_kernel(AttnArgs p, 
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) sum += kpart[w * D + tid];
-            kbar[tid] = sum / (float)p.kv_len;
+            kbar[tid] = p.mean_key ? p.mean_key[((long)b * p.H + h) * D + tid] : sum / (float)p.kv_len;
         }
         __syncthreads();
     }
@@ -789,13 +795,36 @@ extern "C" int mmae_attn_fwd(const void* q, long ldq, const void* k, long ldk, c
     return wide ? launch_fwd<32, 8>(a, stream) : launch_fwd<32, 4>(a, stream);
 }
 
+extern "C" int mmae_attn_max_len(int head_dim, int backward) {
+    if (head_dim != 32 && head_dim != 64) return 0;
+    const size_t row = sizeof(bf16) * 2 * (size_t)(head_dim + 8);  // a K row and a V row (or a Q row and a dO row) of the LDS images
+    const int kv = (int)((ATTN_MAX_LDS - (backward ? sizeof(float) * head_dim : 0)) / row) / 32 * 32;  // attn_fwd / attn_bwd_dq
+    if (!backward) return kv;
+    const int q = (int)(ATTN_MAX_LDS / (row + 2 * sizeof(float))) / 32 * 32;                            // attn_bwd_dkv
+    return q < kv ? q : kv;
+}
+
 extern "C" size_t mmae_attn_bwd_workspace_bytes(int B, int H, int q_len) { return (size_t)B * H * q_len * sizeof(float); }
+
+extern "C" int mmae_attn_bwd_chunk(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* o,
+                                   long ldo, const void* d_o, long lddo, const float* lse, const float* mean_key, void* dq,
+                                   long lddq, void* dk, long lddk, void* dv, long lddv, int B, int H, int q_len, int kv_len,
+                                   int head_dim, float scale, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 extern "C" int mmae_attn_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* o,
                              long ldo, const void* d_o, long lddo, const float* lse, void* dq, long lddq, void* dk, long lddk,
                              void* dv, long lddv, int B, int H, int q_len, int kv_len, int head_dim, float scale,
                              void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return mmae_attn_bwd_chunk(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse, nullptr, dq, lddq, dk, lddk, dv, lddv, B, H, q_len, kv_len,
+                               head_dim, scale, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mmae_attn_bwd_chunk(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* o,
+                                   long ldo, const void* d_o, long lddo, const float* lse, const float* mean_key, void* dq,
+                                   long lddq, void* dk, long lddk, void* dv, long lddv, int B, int H, int q_len, int kv_len,
+                                   int head_dim, float scale, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     AttnArgs a = {};
+    a.mean_key = mean_key;
     a.q = (const bf16*)q; a.ldq = ldq; a.k = (const bf16*)k; a.ldk = ldk; a.v = (const bf16*)v; a.ldv = ldv;
     a.o = (bf16*)o; a.ldo = ldo; a.lse = (float*)lse; a.dO = (const bf16*)d_o; a.lddo = lddo;
     a.dq = (bf16*)dq; a.lddq = lddq; a.dk = (bf16*)dk; a.lddk = lddk; a.dv = (bf16*)dv; a.lddv = lddv;

@@ -269,9 +269,67 @@ def _head_view(t: torch.Tensor, name: str):
     return t.stride(-2)
 
 
+def _seq_chunks(n: int, limit: int):
+    """[start, end) ranges that cover n rows with the fewest chunks of at most `limit` rows, chunk starts on multiples of 32."""
+    parts = -(-n // limit)
+    size = (-(-n // parts) + 31) // 32 * 32
+    return [(s, min(s + size, n)) for s in range(0, n, size)]
+
+
+def _seq_rows(t: torch.Tensor, B: int, n: int, s: int, e: int) -> torch.Tensor:
+    """Rows s..e of every sample of the (row-strided) view t [B*n, W] as a contiguous [B*(e-s), W] tensor."""
+    return t.view(B, n, t.shape[-1])[:, s:e].contiguous().view(B * (e - s), t.shape[-1])
+
+
 def attn_fwd(q, k, v, B, H, q_len, kv_len, head_dim, scale):
-    """q: [B*q_len, >=H*d] view, k/v: [B*kv_len, ...] views (row-strided slices of packed projections).
-    Returns (o [B*q_len, H*d] bf16, lse [B,H,q_len] f32)."""
+    """softmax(q k^T scale) v per (sample, head).  q: [B*q_len, >=H*d] view, k/v: [B*kv_len, ...] views (row-strided slices
+    of packed projections).  Returns (o [B*q_len, H*d] bf16, lse [B,H,q_len] f32).
+    One kernel call keeps the keys and values of a head in LDS (attn_fwd_single); longer key sequences run as one call per
+    chunk of keys, and the partial outputs are merged through their log-sum-exps: o = sum_c exp(lse_c - lse) o_c."""
+    limit = _L().mmae_attn_max_len(head_dim, 0)
+    if kv_len <= limit or limit <= 0:
+        return attn_fwd_single(q, k, v, B, H, q_len, kv_len, head_dim, scale)
+    outs, lses = [], []
+    for s, e in _seq_chunks(kv_len, limit):
+        o_c, lse_c = attn_fwd_single(q, _seq_rows(k, B, kv_len, s, e), _seq_rows(v, B, kv_len, s, e), B, H, q_len, e - s, head_dim, scale)
+        outs.append(o_c)
+        lses.append(lse_c)
+    lse_all = torch.stack(lses)                                 # [chunks, B, H, q_len]
+    lse = torch.logsumexp(lse_all, dim=0)
+    w = torch.exp(lse_all - lse).permute(0, 1, 3, 2).unsqueeze(-1)  # [chunks, B, q_len, H, 1]
+    o = sum(o_c.view(B, q_len, H, head_dim).float() * w_c for o_c, w_c in zip(outs, w))
+    return o.to(BF16).view(B * q_len, H * head_dim), lse
+
+
+def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, q_len, kv_len, head_dim, scale):
+    """Gradients of attn_fwd, written into the (row-strided) views dq / dk / dv.  One kernel call keeps the keys / values and
+    the queries / output gradients of a head in LDS (attn_bwd_single); longer sequences run as one call per (chunk of
+    queries, chunk of keys) with the log-sum-exp and output of the whole row, and the partial gradients are summed in fp32."""
+    limit = _L().mmae_attn_max_len(head_dim, 1)
+    if (q_len <= limit and kv_len <= limit) or limit <= 0:
+        return attn_bwd_single(q, k, v, o, d_o, lse, dq, dk, dv, B, H, q_len, kv_len, head_dim, scale)
+    W = H * head_dim
+    dq32 = torch.zeros((B, q_len, W), dtype=F32, device=q.device)
+    dk32 = torch.zeros((B, kv_len, W), dtype=F32, device=q.device)
+    dv32 = torch.zeros((B, kv_len, W), dtype=F32, device=q.device)
+    k_chunks = [(s, e, _seq_rows(k, B, kv_len, s, e), _seq_rows(v, B, kv_len, s, e)) for s, e in _seq_chunks(kv_len, limit)]
+    mean_key = k.view(B, kv_len, H, head_dim).float().mean(dim=1).contiguous()  # [B, H, d] over the whole row
+    for a0, a1 in _seq_chunks(q_len, limit):
+        qa, oa, doa = (_seq_rows(t, B, q_len, a0, a1) for t in (q, o, d_o))
+        lse_a = lse[:, :, a0:a1].contiguous()
+        for c0, c1, kc, vc in k_chunks:
+            dqa, dkc, dvc = torch.empty_like(qa), torch.empty_like(kc), torch.empty_like(vc)
+            attn_bwd_single(qa, kc, vc, oa, doa, lse_a, dqa, dkc, dvc, B, H, a1 - a0, c1 - c0, head_dim, scale, mean_key=mean_key)
+            dq32[:, a0:a1] += dqa.view(B, a1 - a0, W)
+            dk32[:, c0:c1] += dkc.view(B, c1 - c0, W)
+            dv32[:, c0:c1] += dvc.view(B, c1 - c0, W)
+    dq.view(B, q_len, W).copy_(dq32)
+    dk.view(B, kv_len, W).copy_(dk32)
+    dv.view(B, kv_len, W).copy_(dv32)
+
+
+def attn_fwd_single(q, k, v, B, H, q_len, kv_len, head_dim, scale):
+    """One mmae_attn_fwd call (kv_len up to mmae_attn_max_len(head_dim, 0)); arguments and result as attn_fwd."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _req(t, BF16, f"attn_fwd {n}", contiguous=False)
     o = torch.empty((B * q_len, H * head_dim), dtype=BF16, device=q.device)
@@ -283,17 +341,20 @@ def attn_fwd(q, k, v, B, H, q_len, kv_len, head_dim, scale):
     return o, lse
 
 
-def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, q_len, kv_len, head_dim, scale):
-    """Gradients are written into the (row-strided) views dq / dk / dv."""
+def attn_bwd_single(q, k, v, o, d_o, lse, dq, dk, dv, B, H, q_len, kv_len, head_dim, scale, mean_key=None):
+    """One mmae_attn_bwd call (q_len and kv_len up to mmae_attn_max_len(head_dim, 1)); arguments as attn_bwd.
+    mean_key [B,H,d] f32 (mmae_attn_bwd_chunk): the mean over all keys of the row when k / v are only a chunk of it."""
+    if mean_key is not None:
+        _req(mean_key, F32, "attn_bwd mean_key")
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (d_o, "dO"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
         _req(t, BF16, f"attn_bwd {n}", contiguous=False)
     _req(lse, F32, "attn_bwd lse")
     ws = workspace(_L().mmae_attn_bwd_workspace_bytes(B, H, q_len), q.device)
     with _Timed("attn_bwd", 8.0 * B * H * q_len * kv_len * head_dim):
-        _lib.check(_L().mmae_attn_bwd(_ptr(q), _head_view(q, "q"), _ptr(k), _head_view(k, "k"), _ptr(v), _head_view(v, "v"),
-                                      _ptr(o), _head_view(o, "o"), _ptr(d_o), _head_view(d_o, "dO"), _ptr(lse),
-                                      _ptr(dq), _head_view(dq, "dq"), _ptr(dk), _head_view(dk, "dk"), _ptr(dv), _head_view(dv, "dv"),
-                                      B, H, q_len, kv_len, head_dim, float(scale), _ptr(ws), ws.numel(), _stream()), "attn_bwd")
+        _lib.check(_L().mmae_attn_bwd_chunk(_ptr(q), _head_view(q, "q"), _ptr(k), _head_view(k, "k"), _ptr(v), _head_view(v, "v"),
+                                            _ptr(o), _head_view(o, "o"), _ptr(d_o), _head_view(d_o, "dO"), _ptr(lse), _ptr(mean_key),
+                                            _ptr(dq), _head_view(dq, "dq"), _ptr(dk), _head_view(dk, "dk"), _ptr(dv), _head_view(dv, "dv"),
+                                            B, H, q_len, kv_len, head_dim, float(scale), _ptr(ws), ws.numel(), _stream()), "attn_bwd")
 
 
 # --------------------------------------------------------------------------------------------- masking

@@ -248,34 +248,72 @@ def test_attention_fwd_bwd(ops, attn_bwd_variant, B, H, Nq, Nk, d):
 
 
 def test_attention_length_limit(ops):
-    """The keys (forward, dQ) or queries (dK/dV) of one head live in LDS: the longest sequences that fit 160 KiB run and
-    agree with the reference, one 32-row tile more returns MMAE_ESHAPE before anything is launched."""
+    """The keys (forward, dQ) or queries (dK/dV) of one head live in LDS: the longest sequences that fit 160 KiB run in one
+    call and agree with the reference, one 32-row tile more returns MMAE_ESHAPE before anything is launched; the limits are
+    what mmae_attn_max_len reports."""
     from multimae_amd import _lib
+    lib = _lib.load()
+    assert [lib.mmae_attn_max_len(d, b) for d in (64, 32) for b in (0, 1)] == [544, 544, 1024, 960]
+    assert lib.mmae_attn_max_len(48, 0) == 0
     for d, n_ok in ((64, 544), (32, 960)):
         B, H = 1, 2
         qkv = _randn(B * n_ok, 3 * H * d, seed=30)
         q, k, v = qkv[:, :H * d], qkv[:, H * d:2 * H * d], qkv[:, 2 * H * d:]
-        o, lse = ops.attn_fwd(q, k, v, B, H, n_ok, n_ok, d, d ** -0.5)
+        o, lse = ops.attn_fwd_single(q, k, v, B, H, n_ok, n_ok, d, d ** -0.5)
         f = lambda t, n=n_ok: t.float().reshape(B, n, H, d).permute(0, 2, 1, 3)
         oref, lref = _attn_ref(f(q), f(k), f(v), d ** -0.5)
         assert rel_err(f(o), oref) < 6e-3 and rel_err(lse, lref) < 1e-4
         dqkv = torch.zeros_like(qkv)
-        ops.attn_bwd(q, k, v, o, _randn(B * n_ok, H * d, seed=31), lse, dqkv[:, :H * d], dqkv[:, H * d:2 * H * d], dqkv[:, 2 * H * d:],
-                     B, H, n_ok, n_ok, d, d ** -0.5)
+        ops.attn_bwd_single(q, k, v, o, _randn(B * n_ok, H * d, seed=31), lse, dqkv[:, :H * d], dqkv[:, H * d:2 * H * d], dqkv[:, 2 * H * d:],
+                            B, H, n_ok, n_ok, d, d ** -0.5)
         assert torch.isfinite(dqkv.float()).all() and dqkv.float().abs().sum() > 0
         n_bad = (1153 if d == 64 else 1025)  # ViT-L/16 384^2 without masking at head_dim 64; one row past 1024 at head_dim 32
         big = _randn(B * n_bad, 3 * H * d, seed=32)
         qb, kb, vb = big[:, :H * d], big[:, H * d:2 * H * d], big[:, 2 * H * d:]
         with pytest.raises(_lib.MmaeError, match="LDS"):
-            ops.attn_fwd(qb, kb, vb, B, H, n_bad, n_bad, d, d ** -0.5)
+            ops.attn_fwd_single(qb, kb, vb, B, H, n_bad, n_bad, d, d ** -0.5)
         ob, lb = torch.zeros(B * n_bad, H * d, dtype=torch.bfloat16, device="cuda"), torch.zeros(B, H, n_bad, device="cuda")
         with pytest.raises(_lib.MmaeError, match="LDS"):
-            ops.attn_bwd(qb, kb, vb, ob, ob, lb, torch.zeros_like(qb), torch.zeros_like(kb), torch.zeros_like(vb), B, H, n_bad, n_bad, d,
-                         d ** -0.5)
+            ops.attn_bwd_single(qb, kb, vb, ob, ob, lb, torch.zeros_like(qb), torch.zeros_like(kb), torch.zeros_like(vb), B, H, n_bad, n_bad, d,
+                                d ** -0.5)
     # just past the limit at head_dim 64 (576 rows, the next multiple of 32 after 544)
     qkv = _randn(576, 3 * 64, seed=33)
     with pytest.raises(_lib.MmaeError, match="LDS"):
-        ops.attn_fwd(qkv[:, :64], qkv[:, 64:128], qkv[:, 128:], 1, 1, 576, 576, 64, 0.125)
+        ops.attn_fwd_single(qkv[:, :64], qkv[:, 64:128], qkv[:, 128:], 1, 1, 576, 576, 64, 0.125)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,d", [(2, 4, 1153, 1153, 64),   # ViT-L/16 at 384^2 without masking: 2 x 576 tokens + 1
+                                         (1, 2, 700, 1300, 32),    # cross-attention: only the keys are chunked
+                                         (1, 2, 1000, 99, 32)])    # backward: only the queries are chunked
+def test_attention_beyond_one_call_runs_in_chunks(ops, B, H, Nq, Nk, d):
+    """Sequences longer than one kernel call takes: chunks of keys merged through their log-sum-exps (forward), chunks of
+    queries x keys with summed partial gradients (backward); same tolerances as the single call."""
+    scale = d ** -0.5
+    if Nq == Nk:
+        qkv = _randn(B * Nq, 3 * H * d, seed=40)
+        qv, kv_, vv = qkv[:, :H * d], qkv[:, H * d:2 * H * d], qkv[:, 2 * H * d:]
+        dqkv = torch.zeros_like(qkv)
+        dq, dk, dv = dqkv[:, :H * d], dqkv[:, H * d:2 * H * d], dqkv[:, 2 * H * d:]
+    else:
+        qv, kvbuf = _randn(B * Nq, H * d, seed=41), _randn(B * Nk, 2 * H * d, seed=42)
+        kv_, vv = kvbuf[:, :H * d], kvbuf[:, H * d:]
+        dq, dkv = torch.zeros_like(qv), torch.zeros_like(kvbuf)
+        dk, dv = dkv[:, :H * d], dkv[:, H * d:]
+    o, lse = ops.attn_fwd(qv, kv_, vv, B, H, Nq, Nk, d, scale)
+
+    def heads(t, n):
+        return t.float().reshape(B, n, H, d).permute(0, 2, 1, 3).clone().requires_grad_(True)
+    q4, k4, v4 = heads(qv, Nq), heads(kv_, Nk), heads(vv, Nk)
+    oref, lref = _attn_ref(q4, k4, v4, scale)
+    assert rel_err(o.float().reshape(B, Nq, H, d).permute(0, 2, 1, 3), oref) < 6e-3
+    assert rel_err(lse, lref) < 1e-4
+    d_o = _randn(B * Nq, H * d, seed=43)
+    oref.backward(d_o.float().reshape(B, Nq, H, d).permute(0, 2, 1, 3))
+    ops.attn_bwd(qv, kv_, vv, o, d_o, lse, dq, dk, dv, B, H, Nq, Nk, d, scale)
+    back = lambda t4, n: t4.grad.permute(0, 2, 1, 3).reshape(B * n, H * d)
+    assert rel_err(dq.float(), back(q4, Nq)) < BF16_TOL
+    assert rel_err(dk.float(), back(k4, Nk)) < BF16_TOL
+    assert rel_err(dv.float(), back(v4, Nk)) < BF16_TOL
 
 
 def test_attention_spiked_scores(ops):

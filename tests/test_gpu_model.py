@@ -418,6 +418,32 @@ def test_multivit_encoder_vs_reference_golden():
     assert isinstance(M.create_model("multivit_base", input_adapters=ia, output_adapters=None), M.MultiViT)
 
 
+def test_multivit_longer_than_one_attention_call_vs_oracle():
+    """MultiViT without masking at a size whose token count (2 x 324 + 1 = 649 at head_dim 64) is beyond what one attention
+    call keeps in LDS (544): the encoder runs its attention in chunks; outputs and gradients against the oracle."""
+    import multimae_amd as M
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    cfg = O.make_cfg({"rgb": 3, "depth": 1}, {}, dim=128, depth=2, heads=2, patch=16, image=288)
+    sd = G.perturbed_state(cfg, seed=11)
+    ia = {d: M.PatchedInputAdapter(num_channels=C, stride_level=1, patch_size_full=16, image_size=288) for d, C in cfg["in_domains"].items()}
+    model = M.MultiViT(ia, None, dim_tokens=128, depth=2, num_heads=2)
+    model.load_state_dict(sd, strict=True)
+    model.cuda()
+    x = G.seeded_inputs(cfg, B=2, seed=4)
+    ref_params = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith("pos_emb")) for k, v in sd.items()}
+    ref = O.multivit_forward(ref_params, cfg, x)
+    assert ref.shape == (2, 649, 128)
+    dy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(5))
+    ref.backward(dy)
+    out = model({d: t.cuda() for d, t in x.items()})
+    assert rel_err(out.detach().cpu(), ref.detach()) < BF16_TOL
+    out.backward(dy.cuda())
+    named = dict(model.named_parameters())
+    for n in ("global_tokens", "input_adapters.rgb.proj.weight", "encoder.0.attn.qkv.weight", "encoder.0.attn.proj.bias", "encoder.1.norm1.weight"):
+        assert rel_err(named[n].grad.cpu(), ref_params[n].grad) < BF16_TOL, n
+
+
 def test_checkpoint_round_trip_and_optimizer_interchange(tmp_path):
     """save_model / auto_load_model reproduce the training state exactly; the optimizer entry loads into
     torch.optim.AdamW (and back); the downstream export holds the encoder-side tensors only."""
