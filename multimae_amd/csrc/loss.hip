@@ -41,8 +41,13 @@ __device__ __forceinline__ f32x4 load_pred4(const void* p, long off) {
 }
 
 // grid (nh, B); block (W/4, RR): thread (qx, ry) owns pixel quad qx of rows ry, ry+RR, ... of the C*P rows of this patch row.
-template <bool BF16>
-__global__ void loss_main_kernel(LossArgs a) {
+// NR > 0: the thread owns at most NR rows and keeps their prediction and target quads in registers: every load of the block is
+// issued before the first reduction (one trip to memory instead of one per row: the stores to d_pred keep the compiler from
+// moving later rows' loads ahead of them), and the standardisation statistics (norm_pix: mean, then centred sum of squares) are
+// taken from the registers instead of two more reads of the target.  NR == 0: any number of rows, re-read per pass.
+// Both forms add in the same order, so their results are bitwise equal.
+template <bool BF16, int NR>
+__global__ __launch_bounds__(NR > 0 ? 256 : 1024) void loss_main_kernel(LossArgs a) {
     __shared__ float s_part[1024];                    // one partial per thread
     __shared__ float s_sum[64], s_sq[64], s_err[64];  // per patch column (nw <= 64)
     __shared__ float s_nvalid;
@@ -52,6 +57,23 @@ __global__ void loss_main_kernel(LossArgs a) {
     const int pw_idx = (qx * 4) / a.P;  // patch column of this quad
     const int rows = a.C * a.P;
     const float n_el = (float)(a.C * a.P * a.P);
+    constexpr int NRA = NR > 0 ? NR : 1;
+
+    auto off_of = [&](int r) {
+        const int c = r / a.P, ph = r - c * a.P;
+        return (((long)b * a.C + c) * a.H + ih * a.P + ph) * a.W + qx * 4;
+    };
+    // rows past the thread's last are fetched from its last row and skipped in the sums: no branch between the loads
+    f32x4 tv[NRA], pv[NRA];
+    if (NR > 0) {
+#pragma unroll
+        for (int i = 0; i < NRA; ++i) {
+            const int r = ry + i * RR;
+            const long off = off_of(r < rows ? r : rows - 1);
+            tv[i] = *(const f32x4*)(a.target + off);
+            pv[i] = load_pred4<BF16>(a.pred, off);
+        }
+    }
 
     // fixed-order sum of the partials of every patch column (bitwise reproducible)
     auto patch_reduce = [&](float v, float* dst) {
@@ -81,23 +103,33 @@ __global__ void loss_main_kernel(LossArgs a) {
         __syncthreads();
     }
 
-    auto off_of = [&](int r) {
-        const int c = r / a.P, ph = r - c * a.P;
-        return (((long)b * a.C + c) * a.H + ih * a.P + ph) * a.W + qx * 4;
-    };
     float mean = 0.f, inv_std = 1.f;
     if (a.norm_pix) {
         float s = 0.f;
-        for (int r = ry; r < rows; r += RR) {
-            const f32x4 t = *(const f32x4*)(a.target + off_of(r));
-            s += t[0] + t[1] + t[2] + t[3];
+        if (NR > 0) {
+#pragma unroll
+            for (int i = 0; i < NRA; ++i)
+                if (ry + i * RR < rows) s += tv[i][0] + tv[i][1] + tv[i][2] + tv[i][3];
+        } else {
+            for (int r = ry; r < rows; r += RR) {
+                const f32x4 t = *(const f32x4*)(a.target + off_of(r));
+                s += t[0] + t[1] + t[2] + t[3];
+            }
         }
         patch_reduce(s, s_sum);
         mean = s_sum[pw_idx] / n_el;
         float q = 0.f;
-        for (int r = ry; r < rows; r += RR) {
-            const f32x4 t = *(const f32x4*)(a.target + off_of(r)) - mean;
-            q += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+        if (NR > 0) {
+#pragma unroll
+            for (int i = 0; i < NRA; ++i) {
+                const f32x4 t = tv[i] - mean;
+                if (ry + i * RR < rows) q += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+            }
+        } else {
+            for (int r = ry; r < rows; r += RR) {
+                const f32x4 t = *(const f32x4*)(a.target + off_of(r)) - mean;
+                q += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+            }
         }
         patch_reduce(q, s_sq);
         inv_std = 1.0f / sqrtf(s_sq[pw_idx] / (n_el - 1.0f) + 1e-6f);  // unbiased variance, eps 1e-6
@@ -109,10 +141,8 @@ __global__ void loss_main_kernel(LossArgs a) {
     // and exactly 0 everywhere when no sample has one (the reference then returns a constant 0)
     const float gscale = s_nvalid > 0.f ? (nm > 0.f ? 1.f / s_nvalid : 0.f) * (1.0f / ((float)(a.P * a.P) * nm)) / (float)a.C : 0.f;
     float e = 0.f;
-    for (int r = ry; r < rows; r += RR) {
-        const long off = off_of(r);
-        const f32x4 p4 = load_pred4<BF16>(a.pred, off);
-        const f32x4 t4 = (*(const f32x4*)(a.target + off) - mean) * inv_std;
+    auto one_row = [&](long off, const f32x4& p4, const f32x4& traw) {
+        const f32x4 t4 = (traw - mean) * inv_std;
         const f32x4 d = p4 - t4;
         f32x4 g;
         if (a.kind == 0) {
@@ -131,6 +161,18 @@ __global__ void loss_main_kernel(LossArgs a) {
             } else {
                 *(f32x4*)((float*)a.d_pred + off) = g;
             }
+        }
+    };
+    if (NR > 0) {
+#pragma unroll
+        for (int i = 0; i < NRA; ++i) {
+            const int r = ry + i * RR;
+            if (r < rows) one_row(off_of(r), pv[i], tv[i]);
+        }
+    } else {
+        for (int r = ry; r < rows; r += RR) {
+            const long off = off_of(r);
+            one_row(off, load_pred4<BF16>(a.pred, off), *(const f32x4*)(a.target + off));
         }
     }
     patch_reduce(e * mk, s_err);
@@ -176,8 +218,18 @@ static int masked_loss_launch(int kind, int norm_pix, const void* pred, int pred
     MMAE_CHECK_LAUNCH("loss_count");
     const int qx = W / 4;
     int rr = 256 / qx; if (rr < 1) rr = 1; if (rr > C * patch) rr = C * patch;
-    if (pred_is_bf16) hipLaunchKernelGGL(loss_main_kernel<true>, dim3(a.nh, B), dim3(qx, rr), 0, stream, a);
-    else hipLaunchKernelGGL(loss_main_kernel<false>, dim3(a.nh, B), dim3(qx, rr), 0, stream, a);
+    const int per_thread = (C * patch + rr - 1) / rr;  // rows of the patch row that one thread owns
+#define LOSS_MAIN(NR)                                                                                                      \
+    do {                                                                                                                   \
+        if (pred_is_bf16) hipLaunchKernelGGL((loss_main_kernel<true, NR>), dim3(a.nh, B), dim3(qx, rr), 0, stream, a);      \
+        else hipLaunchKernelGGL((loss_main_kernel<false, NR>), dim3(a.nh, B), dim3(qx, rr), 0, stream, a);                  \
+    } while (0)
+    if (qx * rr > 256) LOSS_MAIN(0);            // (the register forms are built for blocks of up to 256 threads)
+    else if (per_thread <= 4) LOSS_MAIN(4);     // one channel at 224^2
+    else if (per_thread <= 12) LOSS_MAIN(12);   // three channels at 224^2
+    else if (per_thread <= 24) LOSS_MAIN(24);   // three channels at 384^2
+    else LOSS_MAIN(0);
+#undef LOSS_MAIN
     MMAE_CHECK_LAUNCH("loss_main");
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, stream, a);
     MMAE_CHECK_LAUNCH("loss_final");
