@@ -561,7 +561,7 @@ def masked_ce(logits: torch.Tensor, target: torch.Tensor, mask: Optional[torch.T
     d_logits = torch.empty_like(logits) if want_grad else None
     ws = workspace(_L().mmae_masked_ce_workspace_bytes(B, H, W), logits.device)
     moved = logits.numel() * logits.element_size() * (2 if want_grad else 1) + target.numel() * 8
-    with _Timed("masked_ce", 0.0, "ce_main_kernel (with its count / final kernels)", nbytes=moved):
+    with _Timed("masked_ce", 0.0, "ce_main_regs_kernel (with its count / final kernels)", nbytes=moved):
         _lib.check(_L().mmae_masked_ce(_ptr(logits), int(logits.dtype == BF16), _ptr(target), _ptr(mask), B, C_, H, W, patch,
                                        float(label_smoothing), _ptr(loss), _ptr(d_logits), _ptr(ws), ws.numel(), _stream()), "masked_ce")
     return loss, d_logits
