@@ -751,6 +751,27 @@ static int launch_dkv(const AttnArgs& a, hipStream_t s) {
                            a.B * a.H, NW * 64, s, a, nqp, reserved);
 }
 
+// Waves per workgroup for `tiles` 32-row work items (query tiles of the forward and dQ kernels, key tiles of the dK / dV
+// kernel), dealt round-robin to the waves: 4 waves for up to four items, else 8.  One exception, measured: at head_dim 64
+// with LDS images too large for a second workgroup on the CU (ViT-L/16 at 384^2: 289 encoder tokens = 10 items) the
+// workgroup's waves are all the CU has, and 10 or 12 waves that finish in fewer rounds pay (forward 293 -> 265 us, dK / dV
+// 388 -> 347 us, dQ unchanged).  At head_dim 32 (576 decoder queries = 18 items) 9 waves in two rounds were slower than
+// 8 in three (forward 223 -> 249 us): those kernels are bound by what the CU's vector ALU and LDS deliver in total, not by
+// the rounds.
+static int pick_waves(int tiles, size_t lds_bytes, int head_dim) {
+    if (tiles <= 4) return 4;
+    if (head_dim != 64 || lds_bytes <= (size_t)80 * 1024) return 8;
+    int best = 8, best_rounds = (tiles + 7) / 8, best_idle = best_rounds * 8 - tiles;
+    const int cand[2] = {10, 12};
+    for (int nw : cand) {
+        const int rounds = (tiles + nw - 1) / nw, idle = rounds * nw - tiles;
+        if (rounds < best_rounds || (rounds == best_rounds && idle < best_idle)) { best = nw; best_rounds = rounds; best_idle = idle; }
+    }
+    return best;
+}
+#define ATTN_BY_WAVES(launch, D, nw, a, stream)                                                    \
+    ((nw) == 4 ? launch<D, 4>(a, stream) : (nw) == 8 ? launch<D, 8>(a, stream) : (nw) == 10 ? launch<D, 10>(a, stream) : launch<D, 12>(a, stream))
+
 static thread_local int g_bwd_variant = 0;  // 0 = by size, 1 = two kernels, 2 = one kernel whenever the head fits LDS
 extern "C" void mmae_attn_bwd_set_variant(int v) { g_bwd_variant = v; }
 
@@ -790,9 +811,9 @@ extern "C" int mmae_attn_fwd(const void* q, long ldq, const void* k, long ldk, c
     a.o = (bf16*)o; a.ldo = ldo; a.lse = lse; a.B = B; a.H = H; a.q_len = q_len; a.kv_len = kv_len; a.scale = scale;
     int rc = check_common(a, head_dim, "attn_fwd");
     if (rc) return rc;
-    const bool wide = (q_len + 31) / 32 > 4;
-    if (head_dim == 64) return wide ? launch_fwd<64, 8>(a, stream) : launch_fwd<64, 4>(a, stream);
-    return wide ? launch_fwd<32, 8>(a, stream) : launch_fwd<32, 4>(a, stream);
+    const int nw = pick_waves((q_len + 31) / 32, sizeof(bf16) * 2 * (size_t)pad32(kv_len) * (head_dim + 8), head_dim);
+    if (head_dim == 64) return ATTN_BY_WAVES(launch_fwd, 64, nw, a, stream);
+    return ATTN_BY_WAVES(launch_fwd, 32, nw, a, stream);
 }
 
 extern "C" int mmae_attn_max_len(int head_dim, int backward) {
@@ -839,13 +860,14 @@ extern "C" int mmae_attn_bwd_chunk(const void* q, long ldq, const void* k, long 
     // one kernel when Q, dO, K, V of a head fit LDS twice per CU (two blocks keep 16 waves resident)
     if (g_bwd_variant != 1 && fused_lds_bytes(a, head_dim) <= (g_bwd_variant == 2 ? (size_t)ATTN_MAX_LDS : (size_t)80 * 1024))
         return head_dim == 64 ? launch_fused<64, 8>(a, stream) : launch_fused<32, 8>(a, stream);
-    const bool wide_q = (q_len + 31) / 32 > 4, wide_k = (kv_len + 31) / 32 > 4;
+    const int nw_q = pick_waves((q_len + 31) / 32, sizeof(bf16) * 2 * (size_t)pad32(kv_len) * (head_dim + 8), head_dim);   // dQ: K, V in LDS
+    const int nw_k = pick_waves((kv_len + 31) / 32, sizeof(bf16) * 2 * (size_t)pad32(q_len) * (head_dim + 8), head_dim);   // dK / dV: Q, dO in LDS
     if (head_dim == 64) {
-        rc = wide_q ? launch_dq<64, 8>(a, stream) : launch_dq<64, 4>(a, stream);
+        rc = ATTN_BY_WAVES(launch_dq, 64, nw_q, a, stream);
         if (rc) return rc;
-        return wide_k ? launch_dkv<64, 8>(a, stream) : launch_dkv<64, 4>(a, stream);
+        return ATTN_BY_WAVES(launch_dkv, 64, nw_k, a, stream);
     }
-    rc = wide_q ? launch_dq<32, 8>(a, stream) : launch_dq<32, 4>(a, stream);
+    rc = ATTN_BY_WAVES(launch_dq, 32, nw_q, a, stream);
     if (rc) return rc;
-    return wide_k ? launch_dkv<32, 8>(a, stream) : launch_dkv<32, 4>(a, stream);
+    return ATTN_BY_WAVES(launch_dkv, 32, nw_k, a, stream);
 }
