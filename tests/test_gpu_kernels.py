@@ -374,6 +374,34 @@ def test_mask_ties_resolve_to_lower_index(ops):
     assert torch.equal(gk.cpu(), ids_keep) and torch.equal(gr.cpu(), ids_restore) and torch.equal(mask.cpu(), torch.cat(masks, 1))
 
 
+def test_mask_random_shapes_vs_oracle(ops):
+    """Task counts 1..8, task lengths 1..1024 that are mostly not multiples of the 64-lane wavefront, totals up to the 2,048
+    limit (every register-per-lane width of the sort, runs with only padding in them), budgets from 0 to the total, and
+    coarse noise with many equal keys (ties resolve to the lower index): bit-exact against the oracle."""
+    from oracle import multimae_oracle as O
+    rng = np.random.default_rng(7)
+    for case in range(48):
+        T = int(rng.integers(1, 9))
+        cap = (2048 // T)
+        hi = [8, 70, 260, 1024][case % 4]
+        sizes = [int(rng.integers(1, min(hi, cap) + 1)) for _ in range(T)]
+        total = sum(sizes)
+        k = int(rng.choice([0, total, int(rng.integers(0, total + 1))], p=[0.1, 0.1, 0.8]))
+        B = int(rng.integers(1, 6))
+        g = torch.Generator().manual_seed(1000 + case)
+        p, noises, noise_all = O.draw_mask_randomness(B, sizes, 1.0, g)
+        if case % 3 == 0:  # quantised noise: many ties inside the tasks and in the second sort
+            noises = [torch.floor(n * 4) / 4 for n in noises]
+            noise_all = torch.floor(noise_all * 8) / 8
+        masks, ids_keep, ids_restore = O.generate_masks(p, noises, noise_all, k)
+        mask, gk, gr, k32, r32 = ops.mask_generate(p.cuda(), torch.cat(noises, 1).cuda(), noise_all.cuda(), sizes, k)
+        ctx = (case, sizes, k, B)
+        assert torch.equal(gk.cpu(), ids_keep), ctx
+        assert torch.equal(gr.cpu(), ids_restore), ctx
+        assert torch.equal(mask.cpu(), torch.cat(masks, 1)), ctx
+        assert torch.equal(k32.long(), gk) and torch.equal(r32.long(), gr), ctx
+
+
 # ---------------------------------------------------------------------------------------------- optimiser
 def test_adamw_sumsq_cast(ops):
     n, n_decay = 1_000_004, 600_000
