@@ -464,19 +464,20 @@ extern "C" int mmae_build_decoder_emb(const float* const* task_emb_host, const f
 }
 
 // image (bf16 or f32) [B,C,NH*P,NW*P] -> rows bf16 [B*NH*NW, C*P*P] ((c, ph, pw) inner order)
+// One workgroup per (sample, row of patches): its C * P image rows are contiguous runs of NW * P pixels, its NW output rows
+// contiguous runs of C * P * P.  A thread moves four pixels at a time, consecutive threads along the output row (so the
+// stores of a wave are contiguous and its loads are P-pixel segments of P consecutive image rows); all index arithmetic is
+// 32-bit and per workgroup (the grid-stride form spent its time on 64-bit divisions: 3.1 TB/s).
 template <bool F32IN>
-__global__ void patchify_bf16_kernel(const void* __restrict__ img, int B, int C, int NH, int NW, int P, bf16* __restrict__ rows) {
-    const int g_per_row = C * P * P / 4;
-    const long n_all = (long)B * NH * NW * g_per_row;
-    const long H = (long)NH * P, W = (long)NW * P;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += (long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % g_per_row);
-        const long tok = i / g_per_row;
-        const int b = (int)(tok / (NH * NW));
-        const int t = (int)(tok - (long)b * NH * NW);
-        const int nh = t / NW, nw = t - nh * NW;
-        const int n = g * 4, c = n / (P * P), rem = n - c * P * P, ph = rem / P, pw = rem - ph * P;
-        const long src = (((long)b * C + c) * H + nh * P + ph) * W + nw * P + pw;
+__global__ __launch_bounds__(256) void patchify_bf16_kernel(const void* __restrict__ img, int C, int NH, int NW, int P, bf16* __restrict__ rows) {
+    const int nh = blockIdx.x, b = blockIdx.y;
+    const int W = NW * P, H = NH * P, PP = P * P, g_per_tok = C * PP / 4, qp = P / 4;
+    const long img_base = ((long)b * C * H + (long)nh * P) * W;     // (b, c = 0, row nh * P, col 0)
+    bf16* out = rows + ((long)b * NH + nh) * NW * (long)(C * PP);
+    for (int i = threadIdx.x; i < NW * g_per_tok; i += 256) {
+        const int nw = i / g_per_tok, g = i - nw * g_per_tok;       // token of the strip, quad inside its output row
+        const int c = g / (PP / 4), rem = g - c * (PP / 4), ph = rem / qp, q = rem - ph * qp;
+        const long src = img_base + ((long)c * H + ph) * W + nw * P + q * 4;
         bf16x4 o;
         if (F32IN) {
             const f32x4 v = *(const f32x4*)((const float*)img + src);
@@ -484,15 +485,15 @@ __global__ void patchify_bf16_kernel(const void* __restrict__ img, int B, int C,
         } else {
             o = *(const bf16x4*)((const bf16*)img + src);
         }
-        *(bf16x4*)(rows + tok * (C * P * P) + n) = o;
+        *(bf16x4*)(out + (long)nw * (C * PP) + g * 4) = o;
     }
 }
 extern "C" int mmae_patchify_bf16(const void* image, int image_is_f32, int B, int C, int NH, int NW, int P, void* rows,
                                   hipStream_t stream) {
     MMAE_REQUIRE(image && rows && P % 4 == 0, MMAE_EINVAL, "patchify: bad argument");
     if (B == 0) return MMAE_OK;
-    if (image_is_f32) hipLaunchKernelGGL(patchify_bf16_kernel<true>, dim3(2048), dim3(256), 0, stream, image, B, C, NH, NW, P, (bf16*)rows);
-    else hipLaunchKernelGGL(patchify_bf16_kernel<false>, dim3(2048), dim3(256), 0, stream, image, B, C, NH, NW, P, (bf16*)rows);
+    if (image_is_f32) hipLaunchKernelGGL(patchify_bf16_kernel<true>, dim3(NH, B), dim3(256), 0, stream, image, C, NH, NW, P, (bf16*)rows);
+    else hipLaunchKernelGGL(patchify_bf16_kernel<false>, dim3(NH, B), dim3(256), 0, stream, image, C, NH, NW, P, (bf16*)rows);
     MMAE_CHECK_LAUNCH("patchify");
     return MMAE_OK;
 }
