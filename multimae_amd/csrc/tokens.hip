@@ -337,13 +337,15 @@ struct AsmBwdArgs {
     int B, k, G, total, q_start, q_len, Dd, T, ntok;
     bf16* d_ctx; float* part;  // part[b][T+1][Dd]
 };
+// grid (B, column splits): a workgroup owns nv = Dd / 4 / gridDim.y column quads of its sample, so that a sample's work (a
+// few hundred KB read more than once) is spread over several CUs instead of one
 __global__ __launch_bounds__(1024) void decoder_assemble_bwd_kernel(AsmBwdArgs a) {
     const int b = blockIdx.x;
     const int seq = a.k + a.G;
-    const int nv = a.Dd / 4;
+    const int nv = a.Dd / 4 / gridDim.y, c0 = blockIdx.y * nv;
     // d_ctx rows
     for (int i = threadIdx.x; i < seq * nv; i += blockDim.x) {
-        const int j = i / nv, c = i - j * nv;
+        const int j = i / nv, c = c0 + i - j * nv;
         f32x4 v = ((const f32x4*)(a.dc + ((long)b * seq + j) * a.Dd))[c];
         if (j < a.k) {
             const int pos = a.ids_keep[(long)b * a.k + j];
@@ -356,8 +358,8 @@ __global__ __launch_bounds__(1024) void decoder_assemble_bwd_kernel(AsmBwdArgs a
     // partial sums over positions: slot t < T collects d_emb of task t, slot T the mask token.
     // threads are laid out as (column group c, position lane pl); each walks positions pl, pl+PL, ...
     __shared__ float red[1024 * 4];
-    const int PL = blockDim.x / nv;  // position lanes (Dd=256 -> nv=64 -> 16): one workgroup per sample, so many lanes
-    const int c = threadIdx.x % nv, pl = threadIdx.x / nv;
+    const int PL = blockDim.x / nv;  // position lanes (Dd = 256 in four column splits: nv = 16 -> 64 lanes)
+    const int cl = threadIdx.x % nv, c = c0 + cl, pl = threadIdx.x / nv;
     for (int slot = 0; slot <= a.T; ++slot) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         if (pl < PL) {
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(1024) void decoder_assemble_bwd_kernel(AsmBwdArgs a
         __syncthreads();
         if (pl == 0) {
             f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            for (int q = 0; q < PL; ++q) t += *(f32x4*)&red[(q * nv + c) * 4];
+            for (int q = 0; q < PL; ++q) t += *(f32x4*)&red[(q * nv + cl) * 4];
             *(f32x4*)(a.part + ((long)b * (a.T + 1) + slot) * a.Dd + c * 4) = t;
         }
     }
@@ -431,7 +433,8 @@ extern "C" int mmae_decoder_assemble_bwd(const float* d_queries, const float* d_
     if (B == 0) return MMAE_OK;
     AsmBwdArgs a = {d_queries, d_context, ids_keep_i32, ids_restore_i32, B, k, G, T * ntok, q_start, q_len, Dd, T, ntok,
                     (bf16*)d_ctx_bf16, (float*)workspace};
-    hipLaunchKernelGGL(decoder_assemble_bwd_kernel, dim3(B), dim3(1024), 0, stream, a);
+    const int splits = (Dd / 4) % 4 == 0 && Dd >= 128 ? 4 : 1;  // column groups of a sample, one workgroup each
+    hipLaunchKernelGGL(decoder_assemble_bwd_kernel, dim3(B, splits), dim3(1024), 0, stream, a);
     MMAE_CHECK_LAUNCH("decoder_assemble_bwd");
     AsmRedArgs r = {};
     r.part = (const float*)workspace; r.B = B; r.T = T; r.Dd = Dd; r.d_mask_token = d_mask_token; r.accumulate = 0;
