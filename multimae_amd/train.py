@@ -245,11 +245,14 @@ class GradBuckets:
                 cur.wait_stream(self.comm.stream)
             else:
                 src_global = dist.get_global_rank(self.group, src) if self.group is not None else src
-                if self.flat.params.is_cuda and dist.get_backend(self.group) == "gloo":
-                    torch.cuda.synchronize(self.flat.params.device)  # see _launch: nothing pending under gloo's device copies
-                dist.broadcast(self.flat.params, src=src_global, group=self.group)
-                for t in self.flat.frozen:
-                    dist.broadcast(t.data, src=src_global, group=self.group)
+                staged = self.flat.params.is_cuda and dist.get_backend(self.group) == "gloo"  # see _launch
+                for t in [self.flat.params] + [f.data for f in self.flat.frozen]:
+                    if staged:
+                        host = t.cpu()
+                        dist.broadcast(host, src=src_global, group=self.group)
+                        t.copy_(host)
+                    else:
+                        dist.broadcast(t, src=src_global, group=self.group)
         self.flat.sync_bf16()
 
     def _make_hook(self, i):
@@ -297,24 +300,27 @@ class GradBuckets:
                 else:
                     self.after_bucket(b, s, e, torch.cuda.current_stream(buf.device) if buf.is_cuda else None)
             return
-        # gloo (a rehearsal backend here: several ranks on one GPU) copies device tensors to the host on high-priority streams
-        # of its own that wait on this step's streams by events; a high-priority stream waiting for pending work of ordinary
-        # streams can stop the process's queues for good on this ROCm stack (scripts/prio_inversion.py).  So for gloo the
-        # device is drained first (the wait then finds its event complete) and each collective is finished before more work
-        # is queued.  RCCL (ordinary-priority streams) stays asynchronous.
-        serial = buf.is_cuda and dist.get_backend(self.group) == "gloo"
-        if serial:
-            torch.cuda.synchronize(buf.device)
+        # gloo is a rehearsal backend here (several ranks on one GPU, which RCCL refuses).  Given a device tensor it stages it
+        # through the host on high-priority streams of its own that wait on this step's streams by events, and a
+        # high-priority stream waiting for pending work of ordinary streams can stop the process's queues for good on this
+        # ROCm stack (scripts/prio_inversion.py); draining the device before every collective made that rare, not
+        # impossible (two ranks of the ViT-B bench on one GPU still stalled in the wait for a collective in two runs of
+        # five).  So gloo only ever sees host tensors: the bucket is copied to the host on the current stream, reduced
+        # there and copied back, one collective at a time.  RCCL (ordinary-priority streams) stays asynchronous.
+        if buf.is_cuda and dist.get_backend(self.group) == "gloo":
+            if side is not None:
+                torch.cuda.current_stream(buf.device).wait_stream(side)
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            buf.copy_(host)
+            return
         if side is None:
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             side.wait_stream(torch.cuda.current_stream(buf.device))
             with torch.cuda.stream(side):
                 work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        if serial:
-            work.wait()
-        else:
-            self.works.append(work)
+        self.works.append(work)
 
     def reset(self):
         """Forget the completion signals collected so far (nothing may be in flight)."""
