@@ -126,6 +126,12 @@ def pmc_traffic(kernel, config="vitb_rgbd"):
 def main():
     args = parse()
     conf = CONFIGS[args.config]
+    # Only the result line goes to stdout.  Libraries write there on their own when a process group starts (RCCL's version
+    # banner, gloo's connection notes): for the duration of the run file descriptor 1 points at stderr, and rank 0 puts it
+    # back just for the JSON line.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from multimae_amd import functional as Fn
@@ -261,7 +267,10 @@ def main():
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(conf)
+        sys.stdout.flush()
+        os.dup2(result_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

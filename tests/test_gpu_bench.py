@@ -29,6 +29,19 @@ def test_bench_prints_one_json_line_with_roofline():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
 
 
+@pytest.mark.gpu
+def test_bench_stdout_is_the_json_line_alone_when_a_process_group_starts():
+    """RCCL writes a version banner to stdout when a communicator is created (and gloo its connection notes): the result
+    line must still be the only thing on bench.py's stdout.  A one-rank RCCL group stands for the multi-GPU launch."""
+    env = dict(os.environ, MMAE_DP_SINGLE_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[:2000]
+    assert json.loads(lines[0])["n_gpus"] == 1
+
+
 def test_pmc_traffic_lookup_reads_the_committed_table():
     sys.path.insert(0, ROOT)
     import bench
