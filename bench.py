@@ -180,11 +180,16 @@ def main():
         note(f"warm-up step {i} enqueued")
     sync()
     note("warm-up done")
+    # one event per step on the step's stream (no host wait): the spread of the per-step times, beside the mean that `value` uses
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss, task_losses, gn2 = step(batch)
+        marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     note("timed steps done")
     if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
@@ -253,7 +258,9 @@ def main():
         out = {
             "metric": "pretrain images/sec (node), " + conf["name"].split(",")[0],
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "ms_per_step": round(ms, 3), "ms_per_step_median": round(per_step[len(per_step) // 2], 3),
+            "ms_per_step_p10": round(per_step[len(per_step) // 10], 3), "ms_per_step_p90": round(per_step[(9 * len(per_step)) // 10], 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": conf["name"] + ", bf16 operands / fp32 accumulate, fwd + losses + bwd + grad all-reduce + AdamW",
                        "name": args.config, "per_gpu_batch": B, "global_batch": world * B, "num_encoded_tokens": conf["k"],
