@@ -491,12 +491,62 @@ __global__ __launch_bounds__(256) void patchify_bf16_kernel(const void* __restri
         *(bf16x4*)(out + (long)nw * (C * PP) + g * 4) = o;
     }
 }
+// The same through LDS, for strips whose NW output rows fit there (C * P * P * NW bf16 <= 64 KiB): image rows are read as the
+// contiguous runs they are (a thread takes four pixels, consecutive threads along the image row), converted and placed in an
+// LDS image of the NW output rows, which is then written out as the one contiguous block it is.  With small patches (a class
+// map at stride 4: P = 4, 133 channels) the direct form reads 16-byte pieces of 2,128 different image rows per output row and
+// ran at 1.1 TB/s.
+template <bool F32IN>
+__global__ __launch_bounds__(256) void patchify_lds_kernel(const void* __restrict__ img, int C, int NH, int NW, int P, bf16* __restrict__ rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* strip = (bf16*)smem;  // [NW][C * P * P]
+    const int nh = blockIdx.x, b = blockIdx.y;
+    const int W = NW * P, H = NH * P, PP = P * P, row_len = C * PP, qw = W / 4;
+    const long img_base = ((long)b * C * H + (long)nh * P) * W;
+    // four quads per thread and trip, all requested before the first is placed (one trip to memory for the four)
+    constexpr int U = 4;
+    const int n_items = C * P * qw;
+    for (int i0 = threadIdx.x; i0 < n_items; i0 += U * 256) {
+        f32x4 vf[U];
+        bf16x4 vb[U];
+        int dst[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 256 < n_items ? i0 + u * 256 : n_items - 1;
+            const int cr = i / qw, qx = i - cr * qw;    // image row (channel c, row ph of the strip), quad along it
+            const int c = cr / P, ph = cr - c * P;
+            const int px = qx * 4, nw = px / P, pw = px - nw * P;
+            const long src = img_base + ((long)c * H + ph) * W + px;
+            dst[u] = nw * row_len + c * PP + ph * P + pw;
+            if (F32IN) vf[u] = *(const f32x4*)((const float*)img + src);
+            else vb[u] = *(const bf16x4*)((const bf16*)img + src);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u * 256 < n_items) {
+                if (F32IN) vb[u] = (bf16x4){(bf16)vf[u][0], (bf16)vf[u][1], (bf16)vf[u][2], (bf16)vf[u][3]};
+                *(bf16x4*)(strip + dst[u]) = vb[u];
+            }
+        }
+    }
+    __syncthreads();
+    bf16* out = rows + ((long)b * NH + nh) * NW * (long)row_len;
+    for (int i = threadIdx.x; i < NW * row_len / 8; i += 256) *(bf16x8*)(out + i * 8) = *(const bf16x8*)(strip + i * 8);
+}
+
 extern "C" int mmae_patchify_bf16(const void* image, int image_is_f32, int B, int C, int NH, int NW, int P, void* rows,
                                   hipStream_t stream) {
     MMAE_REQUIRE(image && rows && P % 4 == 0, MMAE_EINVAL, "patchify: bad argument");
     if (B == 0) return MMAE_OK;
-    if (image_is_f32) hipLaunchKernelGGL(patchify_bf16_kernel<true>, dim3(NH, B), dim3(256), 0, stream, image, C, NH, NW, P, (bf16*)rows);
-    else hipLaunchKernelGGL(patchify_bf16_kernel<false>, dim3(NH, B), dim3(256), 0, stream, image, C, NH, NW, P, (bf16*)rows);
+    const size_t strip_bytes = sizeof(bf16) * (size_t)NW * C * P * P;
+    if (strip_bytes <= 65536 && (C * P * P) % 8 == 0) {
+        if (image_is_f32) hipLaunchKernelGGL(patchify_lds_kernel<true>, dim3(NH, B), dim3(256), strip_bytes, stream, image, C, NH, NW, P, (bf16*)rows);
+        else hipLaunchKernelGGL(patchify_lds_kernel<false>, dim3(NH, B), dim3(256), strip_bytes, stream, image, C, NH, NW, P, (bf16*)rows);
+    } else if (image_is_f32) {
+        hipLaunchKernelGGL(patchify_bf16_kernel<true>, dim3(NH, B), dim3(256), 0, stream, image, C, NH, NW, P, (bf16*)rows);
+    } else {
+        hipLaunchKernelGGL(patchify_bf16_kernel<false>, dim3(NH, B), dim3(256), 0, stream, image, C, NH, NW, P, (bf16*)rows);
+    }
     MMAE_CHECK_LAUNCH("patchify");
     return MMAE_OK;
 }

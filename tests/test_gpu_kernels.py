@@ -605,6 +605,22 @@ def test_unpatchify_patch4_and_fp32_output(ops):
     assert torch.equal(ops.patchify_bf16(img16, P), rows)
 
 
+@pytest.mark.parametrize("B,C,P,nh,nw", [(3, 3, 16, 14, 14),     # rgb at 224^2
+                                         (2, 1, 16, 14, 14),     # depth
+                                         (2, 133, 4, 14, 14),    # class logits at stride 4 (59.6 KB strip)
+                                         (1, 3, 16, 24, 24),     # 384^2
+                                         (1, 200, 4, 14, 20),    # strip beyond 64 KB: the direct form
+                                         (2, 5, 8, 3, 7)])
+def test_patchify_bit_exact(ops, B, C, P, nh, nw):
+    """image [B,C,nh*P,nw*P] -> rows [B*nh*nw, C*P*P] in (c, ph, pw) order: a pure permutation (plus the bf16 rounding of an
+    fp32 image), so bit-exact against torch for bf16 and fp32 inputs and for both kernel forms."""
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    img = torch.randn(B, C, nh * P, nw * P, generator=g).cuda()
+    ref = img.reshape(B, C, nh, P, nw, P).permute(0, 2, 4, 1, 3, 5).reshape(B * nh * nw, C * P * P).bfloat16()
+    assert torch.equal(ops.patchify_bf16(img, P), ref)
+    assert torch.equal(ops.patchify_bf16(img.bfloat16(), P), ref)
+
+
 def test_adamw_clip_and_skip_on_device(ops):
     """Clipping = torch.nn.utils.clip_grad_norm_ followed by AdamW; a skipped update changes nothing and does not advance
     the bias-correction step (the reference skips optimizer.step(), utils/native_scaler.py:41-46)."""
