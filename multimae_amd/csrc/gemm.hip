@@ -1480,7 +1480,7 @@ extern "C" int mmae_unpatchify_gemm(const void* A, long lda, const void* W, int 
 // gemm_tn: D[N,K] = sum_m X[m,N] * Y[m,K]; both operands are m-major (their rows are the
 // reduction index), so fragments are fetched with the transposing LDS read.
 // ------------------------------------------------------------------------------------------
-#define TN_ROWS 64  // m rows per stage; tile image is [64][128] bf16 = 16 KiB, 256-B rows
+#define TN_ROWS 64  // granularity of an M-split (the 256x256 kernel stages 64 rows at a time, the 128x128 kernel 32)
 
 struct GemmTN {
     const bf16* X; long ldx;  // [M,N]
@@ -1518,32 +1518,41 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int tiles, in
     const int m_begin = split * p.rows_per_split;
     int m_end = m_begin + p.rows_per_split; m_end = m_end < p.M ? m_end : p.M;
 
-    // staging: wave-instruction j fills rows (j*4+wave)*4 .. +3 (16 lanes per 256-B row)
-    int srow[4]; int xcol[4], ycol[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (j * 4 + wave) * 4 + (lane >> 4);
+    // Operand ring: four slots of 32 reduction rows, X image [32][128] bf16 (256-byte rows, 16-column blocks swizzled by
+    // tn_swz) followed by the Y image, filled by LDS-DMA three slots ahead.  Wave-instruction j of a slot fills rows
+    // (j*4 + wave)*4 .. +3, 16 lanes per row; tn_swz(r + 16) == tn_swz(r), so both instructions use the same columns.
+    const int r_st = wave * 4 + (lane >> 4);
+    const bf16* xsrc; const bf16* ysrc;
+    {
         const int c16 = lane & 15;
-        const int nb = (c16 >> 1) ^ tn_swz(r);
-        const int col = nb * 16 + (c16 & 1) * 8;
-        srow[j] = r;
+        const int col = (((c16 >> 1) ^ tn_swz(r_st)) << 4) + (c16 & 1) * 8;
         int xc = n0 + col; xc = xc + 8 <= p.N ? xc : p.N - 8;
         int yc = k0 + col; yc = yc + 8 <= p.K ? yc : p.K - 8;
-        xcol[j] = xc; ycol[j] = yc;
+        xsrc = p.X + (long)(m_begin + r_st) * p.ldx + xc;
+        ysrc = p.Y + (long)(m_begin + r_st) * p.ldy + yc;
     }
-    auto stage = [&](int buf, int mt) {
-        char* sx = smem + buf * 2 * TILE_BYTES;
-        char* sy = sx + TILE_BYTES;
+    const int nh = (m_end - m_begin + 31) / 32;
+    int issued = 0;
+    auto issue = [&]() {  // the next 32 rows into slot issued & 3; rows past the split read zeros
+        char* sx = smem + (issued & 3) * TILE_BYTES + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = mt + srow[j];
-            const bool ok = m < m_end;
-            const void* xs = ok ? (const void*)(p.X + (long)m * p.ldx + xcol[j]) : (const void*)g_zero_page;
-            const void* ys = ok ? (const void*)(p.Y + (long)m * p.ldy + ycol[j]) : (const void*)g_zero_page;
-            glds16(xs, sx + (j * 4 + wave) * 1024);
-            glds16(ys, sy + (j * 4 + wave) * 1024);
+        for (int j = 0; j < 2; ++j) {
+            const int row = issued * 32 + j * 16;
+            const bool ok = m_begin + row + r_st < m_end;
+            // the selected addresses are made opaque so that each copy stays one instruction for all lanes (a branch per
+            // source would issue two where a wave straddles the end of the split, and the counted waits below assume four
+            // per thread and slot)
+            const void* xs = ok ? (const void*)(xsrc + (long)row * p.ldx) : (const void*)g_zero_page;
+            const void* ys = ok ? (const void*)(ysrc + (long)row * p.ldy) : (const void*)g_zero_page;
+            asm volatile("" : "+v"(xs), "+v"(ys));
+            glds16(xs, sx + j * 4096);
+            glds16(ys, sx + 8192 + j * 4096);
         }
+        ++issued;
     };
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (issued < nh) issue();
 
     f32x4 acc[4][4];  // [ki][ni] : D'[k = ki*16 + fq*4 + r][n = ni*16 + fr]
 #pragma unroll
@@ -1562,47 +1571,44 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p, int tiles, in
     for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
-    const int nsteps = (m_end - m_begin + TN_ROWS - 1) / TN_ROWS;
-    if (nsteps > 0) {
-        stage(0, m_begin);
-        __syncthreads();
-    }
-    int cur = 0;
-    for (int st = 0; st < nsteps; ++st) {
-        if (st + 1 < nsteps) stage(cur ^ 1, m_begin + (st + 1) * TN_ROWS);
-        const char* sx = smem + cur * 2 * TILE_BYTES;
-        const char* sy = sx + TILE_BYTES;
+    // Transposing reads of rows 8g + q and 8g + q + 4 (tn_swz of both is q | (g & 1) << 2).  They go through inline asm:
+    // for the builtin the compiler orders the read after every LDS-DMA in flight (s_waitcnt vmcnt(0) in front of the
+    // reads), which turns the run-ahead into a synchronous copy.  The explicit lgkmcnt wait retires them.
+    const int rswz = q | ((g & 1) << 2);
+    const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + (8 * g + q) * 256 + pp * 8;
+    auto frag = [&](unsigned lb, auto off_c, int nb) -> bf16x8 {
+        constexpr int off = decltype(off_c)::value;
+        const unsigned a = lb + ((nb ^ rswz) << 5);
+        bf16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"(off));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(off + 1024));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    for (int hs = 0; hs < nh; ++hs) {
+        // slot hs has landed once all but the two newer slots' loads (four per thread and slot) are back
+        if (hs + 2 < nh) wait_vmcnt<8>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave is done reading slot hs - 1
+        if (issued < nh) issue();      // refill slot hs - 1
+        unsigned lb = lbase + (hs & 3) * TILE_BYTES;
+        asm volatile("" : "+v"(lb));
+        bf16x8 yf[4], xf[4];
 #pragma unroll
-        for (int ms = 0; ms < 2; ++ms) {  // two 32-row reduction steps
-            const int r0 = ms * 32 + 8 * g + q, r1 = r0 + 4;
-            const int s0 = tn_swz(r0), s1 = tn_swz(r1);
-            bf16x8 yf[4], xf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int nbx = wn * 4 + t, nby = wk * 4 + t;
-                const bf16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(sx + r0 * 256 + ((nbx ^ s0) << 5) + pp * 8));
-                const bf16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(sx + r1 * 256 + ((nbx ^ s1) << 5) + pp * 8));
-                const bf16x4 y0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(sy + r0 * 256 + ((nby ^ s0) << 5) + pp * 8));
-                const bf16x4 y1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(sy + r1 * 256 + ((nby ^ s1) << 5) + pp * 8));
-                xf[t] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-                yf[t] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-#pragma unroll
-            for (int ki = 0; ki < 4; ++ki)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[ki], xf[ni], acc[ki][ni], 0, 0, 0);
-            if (do_colsum) {
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) csum[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[ni], csum[ni], 0, 0, 0);
-            }
+        for (int t = 0; t < 4; ++t) {
+            xf[t] = frag(lb, std::integral_constant<int, 0>{}, wn * 4 + t);
+            yf[t] = frag(lb, std::integral_constant<int, 8192>{}, wk * 4 + t);
         }
-        __syncthreads();
-        cur ^= 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[ki], xf[ni], acc[ki][ni], 0, 0, 0);
+        if (do_colsum) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) csum[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[ni], csum[ni], 0, 0, 0);
+        }
     }
 
     float* out = p.out + (long)split * p.slab;
