@@ -283,9 +283,9 @@ def _ln_bwd(dy, x, n_w, n_b, mean, rstd, dres=None, shadow=False):
 # ---------------------------------------------------------------------------------------------
 # pieces shared by the encoder block, the decoder blocks and the decoder head
 # ---------------------------------------------------------------------------------------------
-def _mlp_fwd(x, n_w, n_b, fc1_w, fc1_b, fc2_w, fc2_b):
+def _mlp_fwd(x, n_w, n_b, fc1_w, fc1_b, fc2_w, fc2_b, eps=1e-6):
     """x f32 [M,D] -> x + fc2(gelu(fc1(LN(x)))) and the tensors the backward needs."""
-    ln, mean, rstd = ops.layernorm_fwd(x, n_w, n_b)
+    ln, mean, rstd = ops.layernorm_fwd(x, n_w, n_b, eps)
     w1, w1t = bf16_weights(fc1_w)
     w2, w2t = bf16_weights(fc2_w)
     h, act = ops.gemm_nt(ops.EPI_GELU, ln, w1, fc1_b)
@@ -305,10 +305,10 @@ def _mlp_bwd(g, saved):
     return dx, [dnw, dnb, dw1, db1, dw2, db2]
 
 
-def _self_attn_fwd(x, B, N, heads, n_w, n_b, qkv_w, qkv_b, proj_w, proj_b):
+def _self_attn_fwd(x, B, N, heads, n_w, n_b, qkv_w, qkv_b, proj_w, proj_b, eps=1e-6):
     D = x.shape[-1]
     d = D // heads
-    ln, mean, rstd = ops.layernorm_fwd(x, n_w, n_b)
+    ln, mean, rstd = ops.layernorm_fwd(x, n_w, n_b, eps)
     wq, wqt = bf16_weights(qkv_w)
     wp, wpt = bf16_weights(proj_w)
     qkv = ops.gemm_nt(ops.EPI_BF16, ln, wq, qkv_b)
@@ -334,14 +334,15 @@ def _self_attn_bwd(g, saved):
 
 
 class BlockFn(torch.autograd.Function):
-    """Pre-LN transformer block (multimae/multimae_utils.py:282-285 of the reference), x f32 [B,N,D]."""
+    """Pre-LN transformer block (multimae/multimae_utils.py:282-285 of the reference), x f32 [B,N,D]; eps1 / eps2 are the
+    eps of the two LayerNorms."""
 
     @staticmethod
-    def forward(ctx, x, heads, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b):
+    def forward(ctx, x, heads, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, eps1=1e-6, eps2=1e-6):
         B, N, D = x.shape
         x2 = x.contiguous().reshape(B * N, D)
-        x1, s_att = _self_attn_fwd(x2, B, N, heads, n1w, n1b, qkvw, qkvb, pw, pb)
-        y, s_mlp = _mlp_fwd(x1, n2w, n2b, f1w, f1b, f2w, f2b)
+        x1, s_att = _self_attn_fwd(x2, B, N, heads, n1w, n1b, qkvw, qkvb, pw, pb, eps1)
+        y, s_mlp = _mlp_fwd(x1, n2w, n2b, f1w, f1b, f2w, f2b, eps2)
         ctx.saved = (s_att, s_mlp)
         ctx.shape = (B, N, D)
         return y.reshape(B, N, D)
@@ -353,7 +354,7 @@ class BlockFn(torch.autograd.Function):
         ctx.saved = None
         g1, gm = _mlp_bwd(g.contiguous().reshape(B * N, D), s_mlp)
         g0, ga = _self_attn_bwd(g1, s_att)
-        return (g0.reshape(B, N, D), None, *ga, *gm)
+        return (g0.reshape(B, N, D), None, *ga, *gm, None, None)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -614,8 +615,9 @@ class DecoderHeadFn(torch.autograd.Function):
         ctxt = ops.gemm_nt(ops.EPI_BF16, enc_b, wpc, pc_b).reshape(B, seq, Dd)
         emb = ops.build_decoder_emb([None if e is None else e.detach().contiguous() for e in task_embs], pos_table.contiguous(), ntok, Dd)
         queries, context = ops.decoder_assemble_fwd(ctxt, mask_token.detach().contiguous(), emb, keep32, restore32, k, G, q_start, ntok)
-        qn, qmean, qrstd = ops.layernorm_fwd(queries.reshape(B * ntok, Dd), qn_w, qn_b)
-        cn, cmean, crstd = ops.layernorm_fwd(context.reshape(B * seq, Dd), cn_w, cn_b)
+        eps_q, eps_c, eps_o = meta[7] if len(meta) > 7 else (1e-6, 1e-6, 1e-6)  # of query_norm, context_norm, out_norm
+        qn, qmean, qrstd = ops.layernorm_fwd(queries.reshape(B * ntok, Dd), qn_w, qn_b, eps_q)
+        cn, cmean, crstd = ops.layernorm_fwd(context.reshape(B * seq, Dd), cn_w, cn_b, eps_c)
         wq, wqt = bf16_weights(q_w)
         wkv, wkvt = bf16_weights(kv_w)
         wpr, wprt = bf16_weights(pr_w)
@@ -623,7 +625,7 @@ class DecoderHeadFn(torch.autograd.Function):
         kv = ops.gemm_nt(ops.EPI_BF16, cn, wkv, kv_b)
         o, lse = ops.attn_fwd(q, kv[:, :Dd], kv[:, Dd:], B, heads, ntok, seq, d, d ** -0.5)
         x = ops.gemm_nt(ops.EPI_F32, o, wpr, pr_b)  # the cross-attention output replaces the queries (no residual)
-        y, s_mlp = _mlp_fwd(x, on_w, on_b, f1w, f1b, f2w, f2b)
+        y, s_mlp = _mlp_fwd(x, on_w, on_b, f1w, f1b, f2w, f2b, eps_o)
         ctx.saved = (s_mlp, o, lse, q, kv, qn, cn, queries, context, qmean, qrstd, cmean, crstd, enc_b,
                      wqt, wkvt, wprt, wpct, keep32, restore32, meta, (B, seq, D, Dd), (mask_token, task_embs),
                      (pc_w, pc_b, qn_w, qn_b, cn_w, cn_b, q_w, q_b, kv_w, kv_b, pr_w, pr_b))

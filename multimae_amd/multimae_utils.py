@@ -141,8 +141,8 @@ def layer_norm(norm: nn.LayerNorm, x):
 
 class Block(nn.Module):
     """x + attn(norm1(x)); x + mlp(norm2(x))  (reference: multimae/multimae_utils.py:250-285): one fused autograd node;
-    with a drop rate > 0 in training mode the same kernels as separate nodes with the dropout / stochastic depth of the
-    reference between them."""
+    with a drop rate > 0 in training mode, or a norm_layer other than an affine nn.LayerNorm, the same kernels as separate
+    nodes with the dropout / stochastic depth / norm module of the reference between them."""
 
     def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, drop=0.0, attn_drop=0.0, drop_path=0.0,
                  act_layer=nn.GELU, norm_layer=nn.LayerNorm):
@@ -152,15 +152,19 @@ class Block(nn.Module):
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
-        for n in (self.norm1, self.norm2):
-            if not isinstance(n, nn.LayerNorm) or abs(n.eps - 1e-6) > 1e-12:
-                raise NotImplementedError("the fused block expects nn.LayerNorm(eps=1e-6)")
+        # the fused node normalises with the LayerNorm kernel (affine, over the last dimension, the module's eps); any
+        # other norm module runs as itself between the separate nodes
+        self._ln_kernel = all(isinstance(n, nn.LayerNorm) and n.elementwise_affine and n.bias is not None
+                              and tuple(n.normalized_shape) == (dim,) for n in (self.norm1, self.norm2))
 
     def forward(self, x):
         a, m = self.attn, self.mlp
+        if not self._ln_kernel:
+            x = x + self.drop_path(a(self.norm1(x)))
+            return x + self.drop_path(m(self.norm2(x)))
         if self.training and (a.attn_drop or a.proj_drop or m.drop or isinstance(self.drop_path, DropPath)):
             x = x + self.drop_path(a(layer_norm(self.norm1, x)))
             return x + self.drop_path(m(layer_norm(self.norm2, x)))
         return Fn.BlockFn.apply(x, a.num_heads, self.norm1.weight, self.norm1.bias, a.qkv.weight, _bias_or_zeros(a.qkv),
                                 a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias,
-                                m.fc2.weight, m.fc2.bias)
+                                m.fc2.weight, m.fc2.bias, self.norm1.eps, self.norm2.eps)

@@ -62,6 +62,7 @@ class SpatialOutputAdapter(nn.Module):
         w = self.image_size[1] // (stride_level * self.P_W)
         self.pos_emb = nn.Parameter(build_2d_sincos_posemb(h, w, dim_tokens), requires_grad=False)
 
+        self._ln_kernel = True
         if use_xattn:
             self.decoder = CrossAttention(dim=dim_tokens, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop_rate,
                                           proj_drop=drop_rate)
@@ -69,6 +70,10 @@ class SpatialOutputAdapter(nn.Module):
             self.query_norm = norm_layer(dim_tokens)
             self.out_norm = norm_layer(dim_tokens)
             self.mlp = Mlp(in_features=dim_tokens, hidden_features=int(dim_tokens * mlp_ratio))
+            # the LayerNorm kernel serves affine nn.LayerNorm over the last dimension; any other norm module runs as itself
+            self._ln_kernel = all(isinstance(n, nn.LayerNorm) and n.elementwise_affine and n.bias is not None
+                                  and tuple(n.normalized_shape) == (dim_tokens,)
+                                  for n in (self.context_norm, self.query_norm, self.out_norm))
         if depth > 0:
             dpr = [r.item() for r in torch.linspace(0, drop_path_rate, depth)]  # stochastic depth decay rule
             self.decoder_transformer = nn.Sequential(*[
@@ -108,6 +113,9 @@ class SpatialOutputAdapter(nn.Module):
                                                       self.proj_context.weight, self.proj_context.bias, q_emb, *embs)
         if not self.use_xattn:
             return queries
+        if not self._ln_kernel:
+            x = self.decoder(self.query_norm(queries), self.context_norm(context))
+            return x + self.mlp(self.out_norm(x))
         x = self.decoder(layer_norm(self.query_norm, queries), layer_norm(self.context_norm, context))
         return x + self.mlp(layer_norm(self.out_norm, x))
 
@@ -134,12 +142,12 @@ class SpatialOutputAdapter(nn.Module):
         if enc_b is not None and (enc_b.shape[0] != encoder_tokens.shape[0] * encoder_tokens.shape[1] or enc_b.device != encoder_tokens.device):
             enc_b = None
         dropping = self.use_xattn and self.training and bool(self.decoder.attn_drop or self.decoder.proj_drop)
-        if own_queries or not self.use_xattn or dropping:
+        if own_queries or not self.use_xattn or dropping or not self._ln_kernel:
             x = self._unfused_head(encoder_tokens, keep32, restore32, (k, G, len(tasks), ntok, q_start, own_queries), enc_b, tasks, embs, nh, nw)
             x = self.decoder_transformer(x)
             return Fn.OutProjFn.apply(x, self.out_proj.weight, self.out_proj.bias, self.num_channels, self.P_H, nh, nw, fp32_output)
         d, m = self.decoder, self.mlp
-        meta = (self.num_heads, k, G, len(tasks), ntok, q_start, enc_b)
+        meta = (self.num_heads, k, G, len(tasks), ntok, q_start, enc_b, (self.query_norm.eps, self.context_norm.eps, self.out_norm.eps))
         x = Fn.DecoderHeadFn.apply(
             encoder_tokens, keep32, restore32, meta, self._pos_table(nh, nw), self.mask_token,
             self.proj_context.weight, self.proj_context.bias, self.query_norm.weight, self.query_norm.bias,

@@ -134,3 +134,70 @@ def test_learnable_position_tables_in_flat_storage_take_the_same_gradient():
     for name in ("input_adapters.rgb.pos_emb", "input_adapters.depth.pos_emb", "global_tokens"):
         assert grads[0][name].abs().sum() > 0
         assert torch.equal(grads[0][name], grads[1][name]), name
+
+
+@pytest.mark.parametrize("eps", [1e-5, 0.5])
+def test_layer_norm_eps_comes_from_the_norm_layer(eps, monkeypatch):
+    """norm_layer with another eps than the pretraining configurations' 1e-6 (the reference's Block itself defaults to
+    nn.LayerNorm, eps 1e-5): encoder blocks, decoder head and decoder blocks against the oracle run with that eps.
+    At eps = 0.5 every normalised row shrinks by more than a tenth, so a kernel that ignored the setting fails the bar."""
+    from functools import partial
+    import multimae_amd as M
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    from tests.test_gpu_model import _hip_step
+    cfg = O.small_cfg()
+    sd = G.perturbed_state(cfg, seed=7)
+    x = G.seeded_inputs(cfg, B=4, seed=3)
+    k = 8
+    p, noises, noise_all = O.draw_mask_randomness(4, [16, 16], 1.0, torch.Generator().manual_seed(2))
+    base_losses, base_preds, _, _ = O.step_grads(sd, cfg, x, p, noises, noise_all, k)
+    monkeypatch.setattr(O, "LN_EPS", eps)
+    o_losses, o_preds, o_masks, o_grads = O.step_grads(sd, cfg, x, p, noises, noise_all, k)
+    if eps == 0.5:
+        assert rel_err(o_preds["rgb"], base_preds["rgb"]) > 0.05
+
+    norm = partial(torch.nn.LayerNorm, eps=eps)
+    S = cfg["image"]
+    ia = {d: M.PatchedInputAdapter(num_channels=C, stride_level=1, patch_size_full=cfg["patch"], image_size=S)
+          for d, C in cfg["in_domains"].items()}
+    oa = {name: M.SpatialOutputAdapter(num_channels=C, stride_level=1, patch_size_full=cfg["patch"], dim_tokens=cfg["dec_dim"],
+                                       depth=cfg["dec_depth"], num_heads=cfg["dec_heads"], task=task, norm_layer=norm,
+                                       context_tasks=list(cfg["in_domains"]), image_size=S)
+          for name, (C, task) in cfg["out_domains"].items()}
+    model = M.MultiMAE(ia, oa, num_global_tokens=cfg["num_global"], dim_tokens=cfg["dim"], depth=cfg["depth"],
+                       num_heads=cfg["heads"], norm_layer=norm)
+    model.load_state_dict(sd, strict=True)
+    model.cuda()
+    preds, masks, losses, grads = _hip_step(model, cfg, x, (p, noises, noise_all), k)
+    errs = {f"pred_{t}": rel_err(preds[t].float().cpu(), o_preds[t]) for t in preds}
+    errs.update({f"loss_{t}": abs(losses[t].item() - float(o_losses[t])) / abs(float(o_losses[t])) for t in preds})
+    errs.update({"grad_" + n: rel_err(g.cpu(), o_grads[n]) for n, g in grads.items()})
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print(eps, [(n, f"{e:.2e}") for n, e in worst])
+    bad = {n: e for n, e in errs.items() if not e < BF16_TOL}
+    assert not bad, bad
+
+
+def test_block_with_a_norm_module_that_is_not_an_affine_layer_norm_runs_it_as_a_module(monkeypatch):
+    """Any norm_layer is accepted: what the LayerNorm kernel does not serve (here: LayerNorm without weight and bias)
+    runs as the torch module between the attention and MLP nodes."""
+    from functools import partial
+    import multimae_amd as M
+    from oracle import multimae_oracle as O
+    torch.manual_seed(1)
+    D, heads = 128, 4
+    blk = M.multimae_utils.Block(D, heads, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, elementwise_affine=False)).cuda()
+    assert not blk._ln_kernel and "norm1.weight" not in blk.state_dict()
+    x = torch.randn(4, 40, D, device="cuda", requires_grad=True)
+    y = blk(x)
+    y.square().mean().backward()
+    sd = {"b." + n: t.detach().cpu() for n, t in blk.state_dict().items()}
+    for n in ("norm1", "norm2"):
+        sd[f"b.{n}.weight"], sd[f"b.{n}.bias"] = torch.ones(D), torch.zeros(D)
+    monkeypatch.setattr(O, "LN_EPS", 1e-5)
+    xr = x.detach().cpu().requires_grad_()
+    yr = O.block(xr, sd, "b", heads)
+    yr.square().mean().backward()
+    assert rel_err(y.detach().cpu(), yr.detach()) < BF16_TOL
+    assert rel_err(x.grad.cpu(), xr.grad) < BF16_TOL
