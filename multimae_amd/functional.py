@@ -393,6 +393,29 @@ class LayerNormFn(torch.autograd.Function):
         return dx.reshape(shape), dw, db, None
 
 
+class LinearFn(torch.autograd.Function):
+    """x W^T + b as a node of its own, x f32 or bf16 [..., K] -> f32 [..., N]: serves an Mlp whose activation is not the
+    exact GELU that the fc1 epilogue computes (the activation then runs as its torch module between two of these)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xb = _rows_bf16(x)
+        wb, wt = bf16_weights(w)
+        y = ops.gemm_nt(ops.EPI_F32, xb, wb, b)
+        ctx.saved = (xb, wt, (w, b), x.shape)
+        ctx.in_epi = _grad_epi(x)
+        return y.reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        xb, wt, (w, b), shape = ctx.saved
+        ctx.saved = None
+        gb = _bf16(g.contiguous().reshape(-1, g.shape[-1]))
+        dx = ops.gemm_nt(ctx.in_epi, gb, wt, None)
+        dw, db = _lin_grads(gb, xb, w, b)
+        return dx.reshape(shape), dw, db
+
+
 class MlpFn(torch.autograd.Function):
     """fc2(gelu(fc1(x))), x f32 [..., D] -> f32 [..., D_out]."""
 

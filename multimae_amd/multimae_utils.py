@@ -73,19 +73,24 @@ class DropPath(nn.Module):
 
 
 class Mlp(nn.Module):
-    """fc1 -> exact GELU -> fc2 (reference: multimae/multimae_utils.py:145-169).  Inside Block / SpatialOutputAdapter it
-    runs fused with the LayerNorm and residual around it; called directly it is the bare two-GEMM chain."""
+    """fc1 -> activation -> fc2 (reference: multimae/multimae_utils.py:145-169).  With nn.GELU (the reference's default,
+    exact erf form) the activation is computed in the fc1 product's epilogue, and inside Block / SpatialOutputAdapter the
+    chain runs fused with the LayerNorm and residual around it; any other act_layer runs as its torch module between the
+    two products."""
 
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
         super().__init__()
-        if act_layer is not nn.GELU:
-            raise NotImplementedError("only nn.GELU (erf form) is fused into the GEMM epilogue")
         self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = None if act_layer is nn.GELU else act_layer()
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
         self.drop = drop  # on the output of fc2 only (reference: multimae/multimae_utils.py:162-169)
 
     def forward(self, x):
-        y = Fn.MlpFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        if self.act is None:
+            y = Fn.MlpFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        else:
+            h = self.act(Fn.LinearFn.apply(x, self.fc1.weight, self.fc1.bias))
+            y = Fn.LinearFn.apply(h, self.fc2.weight, self.fc2.bias)
         return F.dropout(y, self.drop, True) if self.training and self.drop else y
 
 
@@ -162,7 +167,7 @@ class Block(nn.Module):
         if not self._ln_kernel:
             x = x + self.drop_path(a(self.norm1(x)))
             return x + self.drop_path(m(self.norm2(x)))
-        if self.training and (a.attn_drop or a.proj_drop or m.drop or isinstance(self.drop_path, DropPath)):
+        if m.act is not None or (self.training and (a.attn_drop or a.proj_drop or m.drop or isinstance(self.drop_path, DropPath))):
             x = x + self.drop_path(a(layer_norm(self.norm1, x)))
             return x + self.drop_path(m(layer_norm(self.norm2, x)))
         return Fn.BlockFn.apply(x, a.num_heads, self.norm1.weight, self.norm1.bias, a.qkv.weight, _bias_or_zeros(a.qkv),

@@ -201,3 +201,32 @@ def test_block_with_a_norm_module_that_is_not_an_affine_layer_norm_runs_it_as_a_
     yr.square().mean().backward()
     assert rel_err(y.detach().cpu(), yr.detach()) < BF16_TOL
     assert rel_err(x.grad.cpu(), xr.grad) < BF16_TOL
+
+
+def test_block_with_another_activation_runs_it_between_the_two_products():
+    """act_layer other than nn.GELU (whose exact form the fc1 epilogue computes): the activation module runs between two
+    GEMM nodes; checked against the same block in fp32 torch math on the host.  (A smooth activation: with ReLU the bf16
+    rounding of a pre-activation next to zero flips its derivative, 2-3 % of the fc1 gradient at this size.)"""
+    from functools import partial
+    import multimae_amd as M
+    from oracle import multimae_oracle as O
+    torch.manual_seed(2)
+    D, heads = 128, 4
+    blk = M.multimae_utils.Block(D, heads, qkv_bias=True, act_layer=torch.nn.SiLU,
+                                 norm_layer=partial(torch.nn.LayerNorm, eps=1e-6)).cuda()
+    assert set(blk.state_dict()) == {f"{m}.{p}" for m in ("norm1", "norm2", "attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")
+                                     for p in ("weight", "bias")}
+    x = torch.randn(4, 40, D, device="cuda", requires_grad=True)
+    y = blk(x)
+    y.square().mean().backward()
+    M.functional.join_side_stream()  # the weight gradients are formed on the second stream
+    sd = {"b." + n: t.detach().cpu().requires_grad_() for n, t in blk.state_dict().items()}
+    xr = x.detach().cpu().requires_grad_()
+    h = xr + O.self_attention(O._ln(xr, sd, "b.norm1"), sd, "b.attn", heads)
+    yr = h + O._lin(torch.nn.functional.silu(O._lin(O._ln(h, sd, "b.norm2"), sd, "b.mlp.fc1")), sd, "b.mlp.fc2")
+    yr.square().mean().backward()
+    errs = {"y": rel_err(y.detach().cpu(), yr.detach()), "dx": rel_err(x.grad.cpu(), xr.grad)}
+    errs.update({n: rel_err(p.grad.cpu(), sd["b." + n].grad) for n, p in blk.named_parameters()})
+    print({n: f"{e:.2e}" for n, e in errs.items()})
+    bad = {n: e for n, e in errs.items() if not e < BF16_TOL}
+    assert not bad, bad
