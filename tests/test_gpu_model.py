@@ -754,3 +754,34 @@ def test_ragged_batches_and_token_counts_vs_oracle(B, k):
     tol = BF16_TOL if B >= 4 else 2 * BF16_TOL
     badg = {n: e for n, e in gerr.items() if not e < tol}
     assert not badg, badg
+
+
+@pytest.mark.parametrize("num_global", [0, 3])
+def test_other_global_token_counts_vs_oracle(num_global):
+    """num_global_tokens other than the pretraining configurations' 1 (the reference appends them after the kept tokens and
+    hands them to every decoder as context without a position or task embedding): none, and three."""
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    cfg = dict(O.small_cfg(), num_global=num_global)
+    sd = G.perturbed_state(cfg, seed=13)
+    assert sd["global_tokens"].shape[1] == num_global
+    B, k = 8, 8
+    x = G.seeded_inputs(cfg, B=B, seed=6)
+    p, noises, noise_all = O.draw_mask_randomness(B, [16, 16], 1.0, torch.Generator().manual_seed(3))
+    o_losses, o_preds, o_masks, o_grads = O.step_grads(sd, cfg, x, p, noises, noise_all, k)
+    model = _build(cfg)
+    model.load_state_dict(sd, strict=True)
+    model.cuda()
+    preds, masks, losses, grads = _hip_step(model, cfg, x, (p, noises, noise_all), k)
+    for d in masks:
+        assert torch.equal(masks[d].cpu(), o_masks[d]), d
+    errs = {f"pred_{t}": rel_err(preds[t].float().cpu(), o_preds[t]) for t in preds}
+    errs.update({f"loss_{t}": abs(losses[t].item() - float(o_losses[t])) / abs(float(o_losses[t])) for t in preds})
+    for n, g in o_grads.items():
+        if g.numel():
+            assert grads.get(n) is not None, n
+            errs["grad_" + n] = rel_err(grads[n].cpu(), g)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print(num_global, [(n, f"{e:.2e}") for n, e in worst])
+    bad = {n: e for n, e in errs.items() if not e < BF16_TOL}
+    assert not bad, bad
