@@ -785,3 +785,55 @@ def test_other_global_token_counts_vs_oracle(num_global):
     print(num_global, [(n, f"{e:.2e}") for n, e in worst])
     bad = {n: e for n, e in errs.items() if not e < BF16_TOL}
     assert not bad, bad
+
+
+def test_other_image_size_than_the_adapters_were_built_for_vs_oracle():
+    """Adapters built for 64 x 64 run on 96 x 64 images (6 x 4 tokens per domain): the input position tables are
+    resampled bicubically, the decoders' bilinearly (reference: multimae/input_adapters.py:129-131,
+    multimae/output_adapters.py:213-218), on a grid that is not square."""
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    cfg = O.small_cfg()
+    sd = G.perturbed_state(cfg, seed=17)
+    B, k, H, W = 8, 11, 96, 64  # eight images: the L1 loss's sign gradient needs terms to average bf16 flips over
+    gen = torch.Generator().manual_seed(9)
+    x = {d: torch.randn(B, C, H, W, generator=gen) for d, C in cfg["in_domains"].items()}
+    p, noises, noise_all = O.draw_mask_randomness(B, [24, 24], 1.0, torch.Generator().manual_seed(4))
+    o_losses, o_preds, o_masks, o_grads = O.step_grads(sd, cfg, x, p, noises, noise_all, k)
+    model = _build(cfg)
+    model.load_state_dict(sd, strict=True)
+    model.cuda()
+    preds, masks, losses, grads = _hip_step(model, cfg, x, (p, noises, noise_all), k)
+    for d in masks:
+        assert masks[d].shape == (B, 24) and torch.equal(masks[d].cpu(), o_masks[d]), d
+    errs = {f"pred_{t}": rel_err(preds[t].float().cpu(), o_preds[t]) for t in preds}
+    errs.update({f"loss_{t}": abs(losses[t].item() - float(o_losses[t])) / abs(float(o_losses[t])) for t in preds})
+    errs.update({"grad_" + n: rel_err(grads[n].cpu(), g) for n, g in o_grads.items()})
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print([(n, f"{e:.2e}") for n, e in worst])
+    assert all(preds[t].shape[-2:] == (H, W) for t in preds)
+    bad = {n: e for n, e in errs.items() if not e < BF16_TOL}
+    assert not bad, bad
+
+
+def test_mask_inputs_false_encodes_every_token_vs_oracle():
+    """forward(mask_inputs=False): every token is kept (in the shuffled order of the mask draw), the masks are all zero
+    (reference: multimae/multimae.py:366-372)."""
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    cfg = O.small_cfg()
+    sd = G.perturbed_state(cfg, seed=19)
+    B = 4
+    x = G.seeded_inputs(cfg, B=B, seed=8)
+    rnd = O.draw_mask_randomness(B, [16, 16], 1.0, torch.Generator().manual_seed(5))
+    o_preds, o_masks = O.forward(sd, cfg, x, *rnd, 32)
+    model = _build(cfg)
+    model.load_state_dict(sd, strict=True)
+    model.cuda().eval()
+    with torch.no_grad():
+        preds, masks = model({d: t.cuda() for d, t in x.items()}, mask_inputs=False, num_encoded_tokens=8, mask_randomness=rnd)
+    for d in masks:
+        assert not masks[d].any() and torch.equal(masks[d].cpu(), o_masks[d]), d
+    errs = {t: rel_err(preds[t].float().cpu(), o_preds[t]) for t in preds}
+    print({t: f"{e:.2e}" for t, e in errs.items()})
+    assert all(e < BF16_TOL for e in errs.values()), errs
