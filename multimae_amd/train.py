@@ -470,15 +470,17 @@ class PretrainStep:
     def __init__(self, model, losses, num_encoded_tokens=98, alphas=1.0, lr=1e-4, weight_decay=0.05, betas=(0.9, 0.95),
                  bucket_mb=64.0, clip_grad=None, skip_grad=None, lr_schedule_values=None, wd_schedule_values=None,
                  start_step=0, sample_tasks_uniformly=False, fp32_output_adapters=(), standardize_depth=False,
-                 eager_optimizer=None, max_steps_in_flight=None):
+                 eager_optimizer=None, max_steps_in_flight=None, loss_on_unmasked=False):
         """clip_grad / skip_grad: max_norm / max_skip_norm of the reference's train_one_epoch
         (run_pretraining_multimae.py:512-519).  lr_schedule_values / wd_schedule_values: per-iteration arrays
-        (cosine_scheduler) applied before each step as at :424-436; iteration = start_step + calls so far."""
+        (cosine_scheduler) applied before each step as at :424-436; iteration = start_step + calls so far.
+        loss_on_unmasked: the losses average over every token instead of the masked ones (:491-496)."""
         self.model, self.losses = model, losses
         self.k, self.alphas = num_encoded_tokens, alphas
         self.clip_grad, self.skip_grad = clip_grad, skip_grad
         self.lr_values, self.wd_values, self.it = lr_schedule_values, wd_schedule_values, start_step
         self.uniform, self.fp32_out = sample_tasks_uniformly, list(fp32_output_adapters)
+        self.loss_on_unmasked = bool(loss_on_unmasked)
         self.standardize_depth = standardize_depth  # truncated standardisation of batch["depth"] (reference :448-459)
         self.flat = FlatParams(model)
         self.buckets = GradBuckets(self.flat, bucket_mb=float(os.environ.get("MMAE_BUCKET_MB", bucket_mb)))  # env: tuning
@@ -536,7 +538,8 @@ class PretrainStep:
         inputs = {d: t for d, t in batch.items() if d in self.model.input_adapters}
         preds, masks = self.model(inputs, num_encoded_tokens=self.k, alphas=self.alphas, mask_randomness=mask_randomness,
                                   sample_tasks_uniformly=self.uniform, fp32_output_adapters=self.fp32_out)
-        task_losses = {t: fn(preds[t], batch[tgt], mask=masks.get(tgt)) for t, (fn, tgt) in self.losses.items()}
+        task_losses = {t: fn(preds[t], batch[tgt], mask=None if self.loss_on_unmasked else masks.get(tgt))
+                       for t, (fn, tgt) in self.losses.items()}
         loss = sum(task_losses.values())
         Fn.mark_unit_upstream(task_losses.values())  # loss is their plain sum: d(loss) / d(task loss) = 1 for every task
         self.buckets.reset()        # completion signals left by a backward pass outside this step

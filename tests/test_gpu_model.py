@@ -837,3 +837,33 @@ def test_mask_inputs_false_encodes_every_token_vs_oracle():
     errs = {t: rel_err(preds[t].float().cpu(), o_preds[t]) for t in preds}
     print({t: f"{e:.2e}" for t, e in errs.items()})
     assert all(e < BF16_TOL for e in errs.values()), errs
+
+
+def test_pretrain_step_loss_on_unmasked_vs_oracle():
+    """PretrainStep(loss_on_unmasked=True): the task losses are taken over every token (the reference's train_one_epoch
+    passes no mask then, run_pretraining_multimae.py:491-496); losses and gradients against the oracle's arithmetic."""
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    from multimae_amd.train import PretrainStep
+    cfg = O.small_cfg()
+    sd = G.perturbed_state(cfg, seed=23)
+    B, k = 8, 8
+    x = G.seeded_inputs(cfg, B=B, seed=4)
+    rnd = O.draw_mask_randomness(B, [16, 16], 1.0, torch.Generator().manual_seed(6))
+    work = {n: v.detach().clone().requires_grad_(not n.endswith(O.FROZEN_SUFFIX)) for n, v in sd.items()}
+    o_preds, _ = O.forward(work, cfg, x, *rnd, k)
+    o_losses = {name: fn(o_preds[name].float(), x[tgt], mask=None, **kw) for name, (fn, tgt, mk, kw) in O.default_loss_table(cfg).items()}
+    names = [n for n in work if work[n].requires_grad]
+    o_grads = dict(zip(names, torch.autograd.grad(sum(o_losses.values()), [work[n] for n in names])))
+
+    model = _build(cfg)
+    model.load_state_dict(sd, strict=True)
+    model.cuda()
+    step = PretrainStep(model, _losses(cfg), num_encoded_tokens=k, lr=0.0, weight_decay=0.0, loss_on_unmasked=True)
+    loss, task_losses, _ = step({d: t.cuda() for d, t in x.items()}, mask_randomness=rnd)
+    errs = {f"loss_{t}": abs(task_losses[t].item() - float(o_losses[t].detach())) / abs(float(o_losses[t].detach())) for t in o_losses}
+    errs.update({"grad_" + n: rel_err(p.grad.cpu(), o_grads[n]) for n, p in model.named_parameters() if p.requires_grad})
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print([(n, f"{e:.2e}") for n, e in worst])
+    bad = {n: e for n, e in errs.items() if not e < BF16_TOL}
+    assert not bad, bad
