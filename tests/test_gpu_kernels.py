@@ -139,6 +139,29 @@ def test_gemm_tn(ops, tn_variant, M, N, K):
     assert rel_err(acc, 2 * x.float().sum(0)) < FP32_TOL and rel_err(out2, 3 * ref) < FP32_TOL
 
 
+def test_gemm_random_ragged_shapes(ops, nt_variant):
+    """A seeded sweep of small and ragged problems (any M, N and K multiples of 8 that fill no tile evenly) through every
+    forward-product variant and, once, through both weight-gradient variants: bias and GELU epilogues against fp32 torch."""
+    rng = np.random.default_rng(20)
+    for i in range(16):
+        M, N, K = int(rng.integers(1, 1500)), 8 * int(rng.integers(1, 90)), 8 * int(rng.integers(1, 60))
+        a, w = _randn(M, K, seed=100 + i), _randn(N, K, seed=200 + i, scale=0.05)
+        bias = _randn(N, seed=300 + i, dtype=torch.float32)
+        lin = a.float() @ w.float().t() + bias
+        assert rel_err(ops.gemm_nt(ops.EPI_F32, a, w, bias), lin) < FP32_TOL, (M, N, K)
+        h, act = ops.gemm_nt(ops.EPI_GELU, a, w, bias)
+        assert rel_err(h.float(), lin) < 4e-3 and rel_err(act.float(), F.gelu(h.float())) < 4e-3, (M, N, K)
+        if nt_variant == 1:
+            for v in (1, 2):
+                ops._L().mmae_gemm_tn_set_variant(v)
+                try:
+                    y = _randn(M, N, seed=400 + i)
+                    dw, cs = ops.gemm_tn(y, a, colsum_out=True)
+                finally:
+                    ops._L().mmae_gemm_tn_set_variant(0)
+                assert rel_err(dw, y.float().t() @ a.float()) < FP32_TOL and rel_err(cs, y.float().sum(0)) < FP32_TOL, (M, N, K, v)
+
+
 def test_gemm_tn_asymmetric(ops):
     M = 256
     x = torch.eye(M, device="cuda", dtype=torch.bfloat16)[:, :128].contiguous()      # [M,128]: picks rows 0..127 of y
