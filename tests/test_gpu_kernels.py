@@ -233,7 +233,8 @@ def attn_bwd_variant(request, ops):
 
 @pytest.mark.parametrize("B,H,Nq,Nk,d", [(3, 12, 99, 99, 64), (2, 8, 196, 196, 32), (2, 8, 196, 99, 32), (1, 2, 17, 17, 32),
                                           (2, 3, 128, 128, 64), (1, 4, 33, 97, 64), (2, 8, 197, 197, 32), (1, 2, 289, 289, 64), (1, 3, 300, 40, 32),
-                                          (1, 2, 250, 250, 64), (1, 2, 520, 520, 32)])
+                                          (1, 2, 250, 250, 64), (1, 2, 520, 520, 32),
+                                          (1, 1, 1, 1, 32), (1, 1, 1, 50, 64), (2, 1, 40, 1, 32), (3, 2, 2, 3, 64)])  # a single query / key
 def test_attention_fwd_bwd(ops, attn_bwd_variant, B, H, Nq, Nk, d):
     scale = d ** -0.5
     # self-attention reads q,k,v out of a packed [B*N, 3*H*d] buffer; cross-attention q from [B*Nq, H*d], k/v from [B*Nk, 2*H*d]
