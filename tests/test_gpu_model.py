@@ -867,3 +867,44 @@ def test_pretrain_step_loss_on_unmasked_vs_oracle():
     print([(n, f"{e:.2e}") for n, e in worst])
     bad = {n: e for n, e in errs.items() if not e < BF16_TOL}
     assert not bad, bad
+
+
+def test_image_domain_at_another_stride_level_vs_oracle():
+    """A plain image domain at stride_level 2 (depth at half resolution: 8 x 8 patches on the same 4 x 4 token grid; reference:
+    multimae/input_adapters.py:64-65, multimae/output_adapters.py:101-102) as input and as output, forward and backward."""
+    import multimae_amd as M
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    out = {"rgb": (3, "rgb"), "depth": (1, "depth")}
+    cfg = O.make_cfg({"rgb": 3, "depth": 1}, out, dim=128, depth=2, heads=4, dec_dim=64, dec_depth=1, dec_heads=2, patch=16,
+                     image=64, stride={"depth": 2})
+    sd = G.perturbed_state(cfg, seed=29)
+    B, k = 8, 8
+    gen = torch.Generator().manual_seed(12)
+    x = {"rgb": torch.randn(B, 3, 64, 64, generator=gen), "depth": torch.randn(B, 1, 32, 32, generator=gen)}
+    rnd = O.draw_mask_randomness(B, [16, 16], 1.0, torch.Generator().manual_seed(7))
+    work = {n: v.detach().clone().requires_grad_(not n.endswith(O.FROZEN_SUFFIX)) for n, v in sd.items()}
+    o_preds, o_masks = O.forward(work, cfg, x, *rnd, k)
+    assert o_preds["depth"].shape == (B, 1, 32, 32)
+    names = [n for n in work if work[n].requires_grad]
+    o_grads = dict(zip(names, torch.autograd.grad(sum(p.square().mean() for p in o_preds.values()), [work[n] for n in names])))
+
+    ia = {d: M.PatchedInputAdapter(num_channels=C, stride_level=cfg["stride"].get(d, 1), patch_size_full=16, image_size=64)
+          for d, C in cfg["in_domains"].items()}
+    oa = {d: M.SpatialOutputAdapter(num_channels=C, stride_level=cfg["stride"].get(d, 1), patch_size_full=16, dim_tokens=64, depth=1,
+                                    num_heads=2, task=t, context_tasks=list(cfg["in_domains"]), image_size=64)
+          for d, (C, t) in out.items()}
+    model = M.MultiMAE(ia, oa, num_global_tokens=1, dim_tokens=128, depth=2, num_heads=4)
+    model.load_state_dict(sd, strict=True)
+    model.cuda()
+    preds, masks = model({d: t.cuda() for d, t in x.items()}, num_encoded_tokens=k, alphas=1.0, mask_randomness=rnd)
+    sum(p.float().square().mean() for p in preds.values()).backward()
+    M.functional.join_side_stream()
+    for d in masks:
+        assert torch.equal(masks[d].cpu(), o_masks[d]), d
+    errs = {f"pred_{t}": rel_err(preds[t].float().cpu(), o_preds[t].detach()) for t in preds}
+    errs.update({"grad_" + n: rel_err(p.grad.cpu(), o_grads[n]) for n, p in model.named_parameters() if p.requires_grad})
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print([(n, f"{e:.2e}") for n, e in worst])
+    bad = {n: e for n, e in errs.items() if not e < BF16_TOL}
+    assert not bad, bad
