@@ -908,3 +908,46 @@ def test_image_domain_at_another_stride_level_vs_oracle():
     print([(n, f"{e:.2e}") for n, e in worst])
     bad = {n: e for n, e in errs.items() if not e < BF16_TOL}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("domains", [{"rgb": 3}, {"rgb": 3, "depth": 1, "normal": 3, "edges": 1, "extra": 2}])
+def test_one_and_five_domains_vs_oracle(domains):
+    """Domain counts other than the pretraining configurations' two or three: a single-domain masked autoencoder, and five
+    image domains (the Dirichlet draw, the joint shuffle and every decoder's context span all of them)."""
+    import multimae_amd as M
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    out = {d: (C, d) for d, C in domains.items()}
+    cfg = O.make_cfg(domains, out, dim=128, depth=2, heads=4, dec_dim=64, dec_depth=1, dec_heads=2, patch=16, image=64)
+    sd = G.perturbed_state(cfg, seed=31)
+    B, T = 8, len(domains)
+    k = 4 * T + 1
+    gen = torch.Generator().manual_seed(14)
+    x = {d: torch.randn(B, C, 64, 64, generator=gen) for d, C in domains.items()}
+    rnd = O.draw_mask_randomness(B, [16] * T, 1.0, torch.Generator().manual_seed(8))
+    work = {n: v.detach().clone().requires_grad_(not n.endswith(O.FROZEN_SUFFIX)) for n, v in sd.items()}
+    o_preds, o_masks = O.forward(work, cfg, x, *rnd, k)
+    o_losses = {d: O.masked_mse(o_preds[d], x[d], mask=o_masks[d], patch_size=16) for d in domains}
+    names = [n for n in work if work[n].requires_grad]
+    o_grads = dict(zip(names, torch.autograd.grad(sum(o_losses.values()), [work[n] for n in names])))
+
+    ia = {d: M.PatchedInputAdapter(num_channels=C, stride_level=1, patch_size_full=16, image_size=64) for d, C in domains.items()}
+    oa = {d: M.SpatialOutputAdapter(num_channels=C, stride_level=1, patch_size_full=16, dim_tokens=64, depth=1, num_heads=2, task=d,
+                                    context_tasks=list(domains), image_size=64) for d, C in domains.items()}
+    model = M.MultiMAE(ia, oa, num_global_tokens=1, dim_tokens=128, depth=2, num_heads=4)
+    model.load_state_dict(sd, strict=True)
+    model.cuda()
+    xg = {d: t.cuda() for d, t in x.items()}
+    preds, masks = model(xg, num_encoded_tokens=k, alphas=1.0, mask_randomness=rnd)
+    losses = {d: M.MaskedMSELoss(patch_size=16, stride=1)(preds[d], xg[d], mask=masks[d]) for d in domains}
+    sum(losses.values()).backward()
+    M.functional.join_side_stream()
+    for d in masks:
+        assert torch.equal(masks[d].cpu(), o_masks[d]), d
+    errs = {f"pred_{d}": rel_err(preds[d].float().cpu(), o_preds[d].detach()) for d in preds}
+    errs.update({f"loss_{d}": abs(losses[d].item() - float(o_losses[d].detach())) / abs(float(o_losses[d].detach())) for d in domains})
+    errs.update({"grad_" + n: rel_err(p.grad.cpu(), o_grads[n]) for n, p in model.named_parameters() if p.requires_grad})
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print(T, [(n, f"{e:.2e}") for n, e in worst])
+    bad = {n: e for n, e in errs.items() if not e < BF16_TOL}
+    assert not bad, bad
