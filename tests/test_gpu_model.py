@@ -951,3 +951,44 @@ def test_one_and_five_domains_vs_oracle(domains):
     print(T, [(n, f"{e:.2e}") for n, e in worst])
     bad = {n: e for n, e in errs.items() if not e < BF16_TOL}
     assert not bad, bad
+
+
+def test_no_qkv_bias_and_another_mlp_ratio_vs_oracle():
+    """qkv_bias=False (no bias on qkv / q / kv anywhere; the kernels then add a zero vector) and mlp_ratio=2 in the encoder
+    and the decoders, forward and backward."""
+    import multimae_amd as M
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    out = {"rgb": (3, "rgb"), "depth": (1, "depth")}
+    cfg = O.make_cfg({"rgb": 3, "depth": 1}, out, dim=128, depth=2, heads=4, dec_dim=64, dec_depth=1, dec_heads=2, patch=16,
+                     image=64, mlp_ratio=2.0)
+    sd = {n: v for n, v in G.perturbed_state(cfg, seed=37).items() if not n.endswith((".qkv.bias", ".q.bias", ".kv.bias"))}
+    assert sd["encoder.0.mlp.fc1.weight"].shape == (256, 128)
+    B, k = 8, 8
+    x = G.seeded_inputs(cfg, B=B, seed=10)
+    rnd = O.draw_mask_randomness(B, [16, 16], 1.0, torch.Generator().manual_seed(9))
+    work = {n: v.detach().clone().requires_grad_(not n.endswith(O.FROZEN_SUFFIX)) for n, v in sd.items()}
+    o_preds, o_masks = O.forward(work, cfg, x, *rnd, k)
+    o_losses = {d: O.masked_mse(o_preds[d], x[d], mask=o_masks[d], patch_size=16) for d in out}
+    names = [n for n in work if work[n].requires_grad]
+    o_grads = dict(zip(names, torch.autograd.grad(sum(o_losses.values()), [work[n] for n in names])))
+
+    ia = {d: M.PatchedInputAdapter(num_channels=C, stride_level=1, patch_size_full=16, image_size=64) for d, C in cfg["in_domains"].items()}
+    oa = {d: M.SpatialOutputAdapter(num_channels=C, stride_level=1, patch_size_full=16, dim_tokens=64, depth=1, num_heads=2, task=t,
+                                    context_tasks=list(cfg["in_domains"]), image_size=64, qkv_bias=False, mlp_ratio=2.0)
+          for d, (C, t) in out.items()}
+    model = M.MultiMAE(ia, oa, num_global_tokens=1, dim_tokens=128, depth=2, num_heads=4, qkv_bias=False, mlp_ratio=2.0)
+    model.load_state_dict(sd, strict=True)
+    model.cuda()
+    xg = {d: t.cuda() for d, t in x.items()}
+    preds, masks = model(xg, num_encoded_tokens=k, alphas=1.0, mask_randomness=rnd)
+    losses = {d: M.MaskedMSELoss(patch_size=16, stride=1)(preds[d], xg[d], mask=masks[d]) for d in out}
+    sum(losses.values()).backward()
+    M.functional.join_side_stream()
+    errs = {f"pred_{d}": rel_err(preds[d].float().cpu(), o_preds[d].detach()) for d in preds}
+    errs.update({f"loss_{d}": abs(losses[d].item() - float(o_losses[d].detach())) / abs(float(o_losses[d].detach())) for d in out})
+    errs.update({"grad_" + n: rel_err(p.grad.cpu(), o_grads[n]) for n, p in model.named_parameters() if p.requires_grad})
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print([(n, f"{e:.2e}") for n, e in worst])
+    bad = {n: e for n, e in errs.items() if not e < BF16_TOL}
+    assert not bad, bad
