@@ -992,3 +992,30 @@ def test_no_qkv_bias_and_another_mlp_ratio_vs_oracle():
     print([(n, f"{e:.2e}") for n, e in worst])
     bad = {n: e for n, e in errs.items() if not e < BF16_TOL}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("dec_depth", [0, 3])
+def test_decoders_without_and_with_three_transformer_blocks_vs_oracle(dec_depth):
+    """SpatialOutputAdapter(depth=0) (the class's default: cross-attention and MLP only) and depth=3."""
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    cfg = dict(O.small_cfg(), dec_depth=dec_depth)
+    sd = G.perturbed_state(cfg, seed=41)
+    B, k = 8, 8
+    x = G.seeded_inputs(cfg, B=B, seed=12)
+    p, noises, noise_all = O.draw_mask_randomness(B, [16, 16], 1.0, torch.Generator().manual_seed(10))
+    o_losses, o_preds, o_masks, o_grads = O.step_grads(sd, cfg, x, p, noises, noise_all, k)
+    model = _build(cfg)
+    assert (len(model.output_adapters["rgb"].decoder_transformer) if dec_depth else
+            isinstance(model.output_adapters["rgb"].decoder_transformer, torch.nn.Identity))
+    model.load_state_dict(sd, strict=True)
+    model.cuda()
+    preds, masks, losses, grads = _hip_step(model, cfg, x, (p, noises, noise_all), k)
+    errs = {f"pred_{t}": rel_err(preds[t].float().cpu(), o_preds[t]) for t in preds}
+    errs.update({f"loss_{t}": abs(losses[t].item() - float(o_losses[t])) / abs(float(o_losses[t])) for t in preds})
+    assert set(grads) == set(o_grads)
+    errs.update({"grad_" + n: rel_err(g.cpu(), o_grads[n]) for n, g in grads.items()})
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print(dec_depth, [(n, f"{e:.2e}") for n, e in worst])
+    bad = {n: e for n, e in errs.items() if not e < BF16_TOL}
+    assert not bad, bad
