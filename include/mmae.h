@@ -52,7 +52,10 @@ int mmae_gemm_nt(int epi, const void* A, long lda, const void* W, long ldw, int 
 /* Kernel choice for mmae_gemm_nt and its two siblings below: 0 = by problem size (default), 1 = always the 128x128
  * two-workgroups-per-CU kernel, 4 = persistent 128x128 (2-stage ring), 5 = 256x256 eight-wave ping-pong kernel (K a
  * multiple of 128, else as 0), 7 = 128x256 four-wave kernel, two workgroups per CU (K a multiple of 64, else as 0).  Like every *_set_* switch of this library it applies to the calling thread's later
- * calls only; for tests and tuning. */
+ * calls only; for tests and tuning.  NOTE: PyTorch runs the backward nodes of a CUDA graph on its autograd engine's device
+ * thread, not on the thread that called backward(): a switch set from the Python main thread reaches the kernels of the
+ * forward pass and of direct calls, but NOT those launched inside loss.backward(), which keep the defaults.  To measure a
+ * variant in backward, set it from inside a backward hook (that runs on the engine's thread) or call the op directly. */
 void mmae_gemm_nt_set_variant(int variant);
 /* The 256x256 kernel may cut the last row panels into 128-row half tiles so that a thin last round of tiles is shared by
  * twice as many CUs (default on); 0 switches that off.  Per calling thread; for tests and tuning. */
@@ -234,7 +237,9 @@ int mmae_masked_loss(int kind, int norm_pix, const void* pred, int pred_is_bf16,
  * per-patch-row partial sums (B * (1 + H / patch) floats) live in a fixed array of MMAE_MASKED_LOSS_STATIC_BYTES inside the
  * library's device image, one copy per GPU, held until the process ends; larger inputs return MMAE_EWORKSPACE.  The call
  * allocates and frees nothing and enqueues the same kernels as mmae_masked_loss, so results are bitwise the same.  Calls
- * on one GPU share the array: calls that overlap (different streams without an ordering between them) race. */
+ * on one GPU share the array: calls that overlap (different streams without an ordering between them) race.
+ * Precondition: the GPU that owns the tensors (and `stream`) is the calling thread's current device; the call checks the
+ * device of `loss` against it and returns MMAE_EINVAL on a mismatch (or when `loss` is not device memory). */
 #define MMAE_MASKED_LOSS_STATIC_BYTES 262144
 int mmae_masked_loss_static(int kind, int norm_pix, const void* pred, int pred_is_bf16, const float* target,
                             const int64_t* mask, int B, int C, int H, int W, int patch, float* loss, void* d_pred,

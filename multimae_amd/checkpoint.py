@@ -23,13 +23,27 @@ def _is_main_process() -> bool:
 def _save_on_master(obj, path: str):
     """Rank 0 writes (reference: save_on_master, utils/checkpoint.py:128-131 there) to a temporary file that is renamed
     into place, so a reader (latest_checkpoint on another rank, a resume after a crash) never sees a partial file;
-    every rank then waits for the write."""
+    every rank then waits for the write.  A failed write (disk full, permissions) removes the temporary file and raises
+    on EVERY rank: rank 0 still reaches the exchange below, so nobody is left waiting in it."""
+    error = None
     if _is_main_process():
         tmp = path + ".tmp.%d" % os.getpid()
-        torch.save(obj, tmp)
-        os.replace(tmp, path)
+        try:
+            torch.save(obj, tmp)
+            os.replace(tmp, path)
+        except Exception as exc:  # noqa: BLE001 - reported to every rank below
+            error = exc
+            try:
+                os.remove(tmp)
+            except OSError:
+                pass
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        box = [None if error is None else f"{type(error).__name__}: {error}"]
+        dist.broadcast_object_list(box, src=0)  # doubles as the barrier
+        if box[0] is not None and error is None:
+            raise RuntimeError(f"rank 0 could not write {path}: {box[0]}")
+    if error is not None:
+        raise error
 
 
 def multivit_pretrained_keys(state_dict_keys: Iterable[str]) -> List[str]:

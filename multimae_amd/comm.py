@@ -26,6 +26,12 @@ class NativeComm:
             else:
                 rank, world = 0, 1
         self.rank, self.world = int(rank), int(world)
+        # One RCCL communicator per process and GPU: beside torch.distributed's own "nccl" group on the same device a
+        # barrier was seen to hang (both communicators' kernels wait for their peers on the process's four hardware
+        # queues).  train.init_distributed_mode starts torch.distributed over gloo when MMAE_COMM=native for this reason.
+        if dist.is_initialized() and dist.get_backend(group) == "nccl":
+            raise _lib.MmaeError("NativeComm: torch.distributed already runs an RCCL ('nccl') group in this process; start "
+                                 "it with backend 'gloo' (the host channel for the communicator id) or use that group")
         ident = C.create_string_buffer(128)
         if self.rank == 0:
             _lib.check(lib.mmae_comm_unique_id(ident), "comm_unique_id")

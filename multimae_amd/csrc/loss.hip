@@ -268,11 +268,18 @@ static __device__ __align__(256) float scratch[MMAE_LOSS_STATIC_FLOATS];
 static float* g_scratch_ptr[MMAE_MAX_DEVICES];  // per device; written once under the mutex
 static std::mutex g_scratch_mutex;
 
-static int static_scratch(float** out) {
+static int static_scratch(float** out, const void* device_ptr) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     MMAE_REQUIRE(e == hipSuccess && dev >= 0 && dev < MMAE_MAX_DEVICES, MMAE_EINVAL, "masked_loss_static: no current device (%s)",
                  hipGetErrorString(e));
+    // The array is per GPU and its address is taken for the calling thread's current device: the tensors (and so the
+    // stream the kernels run on) must live on that device, else the kernels would be handed another GPU's address.
+    hipPointerAttribute_t attr;
+    e = hipPointerGetAttributes(&attr, device_ptr);
+    MMAE_REQUIRE(e == hipSuccess, MMAE_EINVAL, "masked_loss_static: the loss pointer is not device memory (%s)", hipGetErrorString(e));
+    MMAE_REQUIRE(attr.device == dev, MMAE_EINVAL, "masked_loss_static: tensors live on device %d but the current device is %d "
+                 "(make the tensors' device current before the call)", attr.device, dev);
     std::lock_guard<std::mutex> guard(g_scratch_mutex);
     if (!g_scratch_ptr[dev]) {
         void* p = nullptr;
@@ -294,7 +301,7 @@ extern "C" int mmae_masked_loss_static(int kind, int norm_pix, const void* pred,
                  "masked_loss_static: %d images x %d patch rows need %zu bytes of partial sums, the fixed array holds %zu "
                  "(use mmae_masked_loss with a workspace)", B, H / patch, need, sizeof(float) * MMAE_LOSS_STATIC_FLOATS);
     float* ws = nullptr;
-    const int rc = static_scratch(&ws);
+    const int rc = static_scratch(&ws, loss);
     if (rc != MMAE_OK) return rc;
     return masked_loss_launch(kind, norm_pix, pred, pred_is_bf16, target, mask, B, C, H, W, patch, loss, d_pred, ws, stream);
 }

@@ -19,31 +19,76 @@ from . import functional as Fn
 from . import ops
 
 
-def init_distributed_mode(backend: str = "nccl"):
+def init_from_env(backend: str = "nccl"):
     """Environment-variable rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), one process per GPU.
-    Returns (rank, world_size, local_rank). Mirrors init_distributed_mode of the reference (utils/dist.py:66-108 there)."""
+    Returns (rank, world_size, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    _start_group(backend, rank, world, local)
+    return rank, world, local
+
+
+def _start_group(backend, rank, world, gpu, init_method=None, always=False):
     single = os.environ.get("MMAE_DP_SINGLE_RANK") == "1"  # rehearsal: a one-rank group still runs every collective
-    if (world > 1 or single) and not dist.is_initialized():
+    if (world > 1 or single or always) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         native = os.environ.get("MMAE_COMM") == "native"
+        kw = {} if init_method in (None, "", "env://") else {"init_method": init_method}
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(gpu)
             # the step's own streams are chosen by timing idle kernels on candidates (functional.concurrent_stream): do it
             # before the communicator exists, so the timing never runs beside a resident collective kernel
-            Fn.prepare_streams(torch.device("cuda", local), 2)
+            Fn.prepare_streams(torch.device("cuda", gpu), 2)
         if backend == "nccl" and not native:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", gpu), **kw)
         else:
             # With the C ABI's RCCL driver (MMAE_COMM=native) torch.distributed is the host-side control plane only (the
             # communicator id, barriers, scalars): gloo.  The driver's communicator then is the only RCCL communicator of
-            # the process; beside a second one (torch's "nccl" group on the same GPU) a barrier was seen to hang.
-            dist.init_process_group(backend="gloo" if backend == "nccl" else backend, rank=rank, world_size=world)
+            # the process (NativeComm refuses to be built beside a torch "nccl" group on the same GPU).
+            dist.init_process_group(backend="gloo" if backend == "nccl" else backend, rank=rank, world_size=world, **kw)
         dist.barrier()
-    return rank, world, local
+
+
+def init_distributed_mode(args="nccl"):
+    """The reference's call shape (utils/dist.py:66-108 there; called as utils.init_distributed_mode(args) at
+    run_pretraining_multimae.py:144): reads args.dist_on_itp / args.gpus / args.dist_url and the launcher's environment
+    (OpenMPI, torchrun's RANK / WORLD_SIZE / LOCAL_RANK, or SLURM_PROCID), sets args.rank / world_size / gpu / distributed /
+    dist_backend, starts the RCCL group ("nccl" is RCCL on ROCm) and returns None; without a launcher it sets
+    args.distributed = False.  Given a backend string instead it is init_from_env(backend) and returns that tuple."""
+    if isinstance(args, str):
+        return init_from_env(args)
+    env = os.environ
+    gpus = getattr(args, "gpus", None)
+
+    def pick(i):  # args.gpus[local rank]; the argument parser's placeholder default ([-1]) means "the local rank itself"
+        g = gpus[i] if isinstance(gpus, (list, tuple)) and i < len(gpus) else None
+        return i if g is None or g < 0 else g
+    if getattr(args, "dist_on_itp", False):
+        args.rank, args.world_size = int(env["OMPI_COMM_WORLD_RANK"]), int(env["OMPI_COMM_WORLD_SIZE"])
+        args.gpu = pick(int(env["OMPI_COMM_WORLD_LOCAL_RANK"]))
+        args.dist_url = "tcp://%s:%s" % (env["MASTER_ADDR"], env["MASTER_PORT"])
+        env["LOCAL_RANK"], env["RANK"], env["WORLD_SIZE"] = str(args.gpu), str(args.rank), str(args.world_size)
+    elif "RANK" in env and "WORLD_SIZE" in env:
+        args.rank, args.world_size = int(env["RANK"]), int(env["WORLD_SIZE"])
+        args.gpu = pick(int(env["LOCAL_RANK"]))
+    elif "SLURM_PROCID" in env:
+        args.rank = int(env["SLURM_PROCID"])
+        args.world_size = int(env.get("SLURM_NTASKS", getattr(args, "world_size", 1) or 1))
+        args.gpu = pick(args.rank % max(torch.cuda.device_count(), 1))
+    else:
+        print("Not using distributed mode")
+        args.distributed = False
+        return None
+    args.distributed = True
+    args.dist_backend = getattr(args, "dist_backend", None) or "nccl"
+    if args.dist_backend == "nccl":
+        torch.cuda.set_device(args.gpu)
+    print("| distributed init (rank {}): {}, gpu {}".format(args.rank, getattr(args, "dist_url", "env://"), args.gpu), flush=True)
+    # the reference starts a group for any world size, one rank included
+    _start_group(args.dist_backend, args.rank, args.world_size, args.gpu, getattr(args, "dist_url", None), always=True)
+    return None
 
 
 def split_decay(model: torch.nn.Module):

@@ -1,6 +1,7 @@
 """The helpers the reference's training script takes from its ``utils`` package for the step itself
 (run_pretraining_multimae.py:38,45-46,53,144,180-181,228,233,262,330,411-412 there), over this package's runtime.
-Logging, data loading and argument parsing are not part of the step and are not provided."""
+Data loading and argument parsing are not part of the step and are not provided; the meters the loop wraps around
+the step (MetricLogger, SmoothedValue, a WandbLogger without a back end) are in .logger."""
 from typing import Iterator, Optional
 
 import torch
@@ -8,8 +9,9 @@ import torch.distributed as dist
 
 from . import checkpoint as _ckpt
 from .checkpoint import save_model_for_downstream_tasks  # noqa: F401
+from .logger import MetricLogger, SmoothedValue, WandbLogger  # noqa: F401
 from .multimae import create_model  # noqa: F401
-from .train import FlatAdamW, FlatParams, GradBuckets, cosine_scheduler, init_distributed_mode  # noqa: F401
+from .train import FlatAdamW, FlatParams, GradBuckets, cosine_scheduler, init_distributed_mode, init_from_env  # noqa: F401
 
 
 def is_dist_avail_and_initialized() -> bool:
@@ -102,6 +104,22 @@ class NativeScalerWithGradNormCount:
         pass
 
 
+def plain_args(args):
+    """The run configuration as a dict of plain values: what checkpoint["args"] holds here.  The reference pickles the
+    argument object itself (utils/checkpoint.py:122 there), which a weights_only load refuses; the fields a resumed run
+    reads (numbers, strings, flags, lists of them) survive as they are."""
+    plain = (int, float, str, bool, type(None))
+    out = {}
+    for k, v in vars(args).items():
+        if k.startswith("_"):
+            continue
+        if isinstance(v, plain):
+            out[k] = v
+        elif isinstance(v, (list, tuple)) and all(isinstance(e, plain) for e in v):
+            out[k] = list(v)
+    return out
+
+
 def save_model(*pos, args=None, epoch=None, model=None, model_without_ddp=None, optimizer=None, loss_scaler=None,
                model_ema=None, **kw):
     """checkpoint.save_model, also in the reference's call shape save_model(args=, epoch=, model=, model_without_ddp=,
@@ -114,7 +132,7 @@ def save_model(*pos, args=None, epoch=None, model=None, model_without_ddp=None, 
         raise NotImplementedError("model_ema is not part of the pretraining step")
     net = model_without_ddp if model_without_ddp is not None else model
     scaler_state = loss_scaler.state_dict() if loss_scaler is not None else None
-    path = _ckpt.save_model(str(args.output_dir), epoch, net, optimizer, args=None, scaler_state=scaler_state)
+    path = _ckpt.save_model(str(args.output_dir), epoch, net, optimizer, args=plain_args(args), scaler_state=scaler_state)
     _ckpt.save_model_for_downstream_tasks(str(args.output_dir), str(getattr(args, "wandb_run_name", "run")), epoch, net)
     return path
 

@@ -100,6 +100,28 @@ def test_compat_aliases():
         for name in ("get_world_size", "get_rank", "is_main_process", "cosine_scheduler", "auto_load_model", "save_model",
                      "init_distributed_mode"):
             assert callable(getattr(utils, name)), name
+        # the meters of the loop (run_pretraining_multimae.py:395,411-421,524-557) and the launcher-less call of :144
+        from types import SimpleNamespace
+        ml = utils.MetricLogger(delimiter="  ")
+        ml.add_meter("lr", utils.SmoothedValue(window_size=1, fmt="{value:.6f}"))
+        seen = []
+        for i, item in enumerate(ml.log_every([10, 11, 12], 2, "Epoch: [0]")):
+            seen.append(item)
+            ml.update(loss=torch.tensor(float(i)), lr=1e-3, skipped=None)
+        ml.synchronize_between_processes()  # no group: a no-op
+        assert seen == [10, 11, 12] and ml.loss.count == 3 and ml.loss.global_avg == 1.0 and ml.loss.median == 1.0
+        assert str(ml.lr) == "0.001000" and "loss: 1.0000 (1.0000)" in str(ml) and "skipped" not in ml.meters
+        with pytest.raises(AttributeError):
+            ml.nothing_here
+        wb = utils.WandbLogger(SimpleNamespace(wandb_project="p"))
+        wb.set_step(5); wb.set_step(); wb.update({"loss": torch.tensor(2.0), "x": None}); wb.flush(); wb.finish()
+        assert wb.step == 6 and wb.last == {"loss": 2.0}
+        launcher = {k: os.environ.pop(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SLURM_PROCID") if k in os.environ}
+        try:
+            args = SimpleNamespace(dist_on_itp=False, gpus=[-1], dist_url="env://")
+            assert utils.init_distributed_mode(args) is None and args.distributed is False
+        finally:
+            os.environ.update(launcher)
     finally:
         compat.uninstall(prev)
     assert sys.modules.get("multimae") is not multimae_amd
@@ -149,9 +171,18 @@ def test_flat_params_layout():
 
 def _dp_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
-    from multimae_amd.train import FlatParams, GradBuckets, init_distributed_mode
-    r, w, _ = init_distributed_mode("gloo")
-    assert (r, w) == (rank, world)
+    from types import SimpleNamespace
+    from multimae_amd import utils as U
+    from multimae_amd.train import FlatParams, GradBuckets
+    # the reference's call shape (utils/dist.py:66-108, run_pretraining_multimae.py:144): fields set on the argument object
+    args = SimpleNamespace(dist_on_itp=False, gpus=[-1], dist_url="env://", dist_backend="gloo", world_size=1)
+    assert U.init_distributed_mode(args) is None
+    assert (args.rank, args.world_size, args.gpu, args.distributed, args.dist_backend) == (rank, world, rank, True, "gloo")
+    assert (U.get_rank(), U.get_world_size(), U.is_main_process()) == (rank, world, rank == 0)
+    meter = U.MetricLogger()
+    meter.update(loss=float(rank + 1))           # rank 0: 1.0, rank 1: 2.0
+    meter.synchronize_between_processes()        # count and total are summed over the ranks (utils/logger.py:46-57)
+    assert meter.loss.count == world and meter.loss.global_avg == 1.5
     torch.manual_seed(0)
     m = _Toy()
     flat = FlatParams(m)
@@ -245,6 +276,54 @@ def test_world2_start_broadcast_accumulation_and_master_only_save(tmp_path):
     assert files == ["checkpoint-3.pth", "start.pt"], files
     ck = torch.load(got["path"], weights_only=True)
     assert all(torch.equal(ck["model"][k], v) for k, v in got["state"].items())
+
+
+def _failing_save_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from multimae_amd import checkpoint as CK
+    from multimae_amd.train import init_from_env
+    init_from_env("gloo")
+    target = os.path.join(out_dir, "missing_dir", "x.pth")  # rank 0's torch.save fails: the directory does not exist
+    try:
+        CK._save_on_master({"a": torch.zeros(1)}, target)
+        raised = ""
+    except Exception as exc:  # noqa: BLE001
+        raised = type(exc).__name__
+    with open(os.path.join(out_dir, f"r{rank}.txt"), "w") as f:
+        f.write(raised)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_failed_checkpoint_write_raises_on_every_rank_and_leaves_no_partial_file(tmp_path):
+    mp.spawn(_failing_save_worker, args=(2, 29800 + os.getpid() % 200, str(tmp_path)), nprocs=2, join=True)
+    got = [open(tmp_path / f"r{r}.txt").read() for r in range(2)]
+    assert got[0] and got[1] == "RuntimeError", got  # nobody hung in the exchange; rank 1 learnt of rank 0's failure
+    assert sorted(os.listdir(tmp_path)) == ["r0.txt", "r1.txt"]
+
+
+def test_reference_shape_save_model_keeps_the_run_configuration(tmp_path):
+    """save_model(args=, epoch=, model=, model_without_ddp=, optimizer=, loss_scaler=) stores the argument object's plain
+    fields under "args" (utils/checkpoint.py:122 of the reference stores the object), loadable with weights_only=True."""
+    from types import SimpleNamespace
+    from multimae_amd import utils as U
+    m = _Toy()
+    args = SimpleNamespace(output_dir=str(tmp_path), wandb_run_name="r", batch_size=256, blr=1e-4, in_domains=["rgb", "depth"],
+                           standardize_depth=True, resume="", device=torch.device("cpu"), _private=1)
+    path = U.save_model(args=args, epoch=7, model=m, model_without_ddp=m, optimizer=None, loss_scaler=U.NativeScalerWithGradNormCount())
+    ck = torch.load(path, weights_only=True)
+    assert ck["epoch"] == 7 and ck["scaler"] == {"scale": 1.0}
+    assert ck["args"] == {"output_dir": str(tmp_path), "wandb_run_name": "r", "batch_size": 256, "blr": 1e-4,
+                          "in_domains": ["rgb", "depth"], "standardize_depth": True, "resume": ""}
+
+
+def test_native_comm_refuses_to_share_a_gpu_with_a_torch_rccl_group(monkeypatch):
+    from multimae_amd import _lib, comm
+    monkeypatch.setattr(comm._lib, "load", lambda: None)
+    monkeypatch.setattr(comm.dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(comm.dist, "get_backend", lambda group=None: "nccl")
+    with pytest.raises(_lib.MmaeError, match="RCCL"):
+        comm.NativeComm(rank=0, world=1)
 
 
 def test_create_optimizer_takes_the_references_call_shape():

@@ -57,3 +57,7 @@ def test_static_scratch_masked_loss_equals_the_workspace_entry_point():
     ptr = C.c_void_p(first[1].data_ptr())
     rc = fn(0, 0, ptr, 1, ptr, None, 1 << 20, 3, 224, 224, 16, ptr, None, None)
     assert rc == -3 and b"fixed array" in lib.mmae_last_error()
+    # tensors that are not on the current device (here: a host buffer for the loss) are refused before any launch
+    host_loss = (C.c_float * 1)()
+    rc = fn(0, 0, ptr, 1, ptr, None, 4, 3, 224, 224, 16, C.cast(host_loss, C.c_void_p), None, None)
+    assert rc == -1 and b"masked_loss_static" in lib.mmae_last_error()
