@@ -53,6 +53,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--comm", choices=("torch", "native"), default=None,
+                    help="gradient exchange for N > 1: torch.distributed's RCCL group (default) or the C ABI's own RCCL "
+                         "communicator (mmae_comm_*); sets MMAE_COMM")
+    ap.add_argument("--no-standardize-depth", action="store_true",
+                    help="leave the truncated depth standardisation (the reference's default, on) out of the step")
     return ap.parse_args()
 
 
@@ -126,6 +131,8 @@ def pmc_traffic(kernel, config="vitb_rgbd"):
 def main():
     args = parse()
     conf = CONFIGS[args.config]
+    if args.comm is not None:
+        os.environ["MMAE_COMM"] = "native" if args.comm == "native" else "torch"
     # Only the result line goes to stdout.  Libraries write there on their own when a process group starts (RCCL's version
     # banner, gloo's connection notes): for the duration of the run file descriptor 1 points at stderr, and rank 0 puts it
     # back just for the JSON line.
@@ -154,8 +161,18 @@ def main():
     torch.manual_seed(0 + rank)  # seed + rank before the model is built, as the reference; rank 0's weights are broadcast
     model = build_multimae(conf["model"], in_domains=conf["in_domains"], out_domains=conf["out_domains"],
                            image_size=conf["image"]).to(dev)
+    # standardize_depth: the reference's default (pretrain_argparser.py:20, applied at run_pretraining_multimae.py:448-459)
     step = PretrainStep(model, build_losses(conf["out_domains"]), num_encoded_tokens=conf["k"], alphas=1.0, lr=1e-4,
-                        weight_decay=0.05, fp32_output_adapters=conf["fp32_out"])
+                        weight_decay=0.05, fp32_output_adapters=conf["fp32_out"],
+                        standardize_depth=not args.no_standardize_depth)
+    comm_info = step.buckets.describe()
+    comm_info["requested"] = os.environ.get("MMAE_COMM", "torch")
+    comm_info["eager_optimizer"] = bool(step.eager)
+    print(f"[bench rank {rank}] gradient exchange: {comm_info['backend']} over {comm_info['ranks_seen']} rank(s), "
+          f"{comm_info['buckets']} buckets, {comm_info['bytes_per_step'] / 1e6:.1f} MB per step, optimizer "
+          f"{'bucket by bucket' if step.eager else 'at the end of the step'}", file=sys.stderr, flush=True)
+    if comm_info["ranks_seen"] != world:
+        raise SystemExit(f"rank {rank}: the communicator spans {comm_info['ranks_seen']} ranks, the launcher started {world}")
     torch.manual_seed(1234 + rank)  # per-rank data / mask randomness
     B = args.batch or conf["batch"]
     batch = synthetic_batch(conf, B, dev)
@@ -180,6 +197,7 @@ def main():
         note(f"warm-up step {i} enqueued")
     sync()
     note("warm-up done")
+    step.buckets.exposed.clear()
     # one event per step on the step's stream (no host wait): the spread of the per-step times, beside the mean that `value` uses
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
@@ -190,6 +208,9 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    # the part of the gradient exchange that backward did not hide: how long the step's stream sat in the final wait
+    exposed = [a.elapsed_time(b) for a, b in step.buckets.exposed]
+    comm_info["exposed_ms_per_step"] = round(sum(exposed) / len(exposed), 3) if exposed else 0.0
     note("timed steps done")
     if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
@@ -212,9 +233,18 @@ def main():
         Fn.SIDE_STREAM_DW = Fn.DECODER_STREAMS = False
         if rank == 0:
             ops.PROFILE = []
+        step.buckets.timing = []  # an event pair around every bucket's collective, on the stream it is issued from
         for _ in range(2):
             step(batch)
         sync()
+        spans = [(b, a.elapsed_time(c)) for b, a, c in step.buckets.timing]
+        step.buckets.timing = None
+        comm_info["allreduce_ms_per_step"] = round(sum(ms_ for _, ms_ in spans) / 2, 3)
+        comm_info["allreduce_ms_per_bucket"] = [round(sum(ms_ for b, ms_ in spans if b == i) / 2, 3)
+                                                for i in range(comm_info["buckets"])]
+        if comm_info["allreduce_ms_per_step"] > 0:
+            comm_info["allreduce_bus_gbps"] = round(2 * (world - 1) / world * comm_info["bytes_per_step"]
+                                                    / comm_info["allreduce_ms_per_step"] / 1e6, 1)
         note("per-kernel timing steps done")
         Fn.SIDE_STREAM_DW, Fn.DECODER_STREAMS = side, dec
     if not args.no_roofline and rank == 0:
@@ -272,6 +302,8 @@ def main():
         }
         if roof is not None:
             out["roofline"] = roof
+        if world > 1 or comm_info["enabled"]:
+            out["comm"] = comm_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(conf)
         sys.stdout.flush()

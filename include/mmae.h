@@ -295,6 +295,8 @@ int mmae_comm_unique_id(void* id_host);
 int mmae_comm_init(const void* id_host, int rank, int world, void** handle);
 int mmae_comm_allreduce_bucket(void* handle, void* ptr, size_t count, int dtype, mmae_stream_t stream);
 int mmae_comm_broadcast(void* handle, void* ptr, size_t count, int dtype, int root, mmae_stream_t stream);
+/* rank and rank count as the RCCL communicator itself reports them (ncclCommUserRank / ncclCommCount) */
+int mmae_comm_info(void* handle, int* rank_host, int* world_host);
 int mmae_comm_destroy(void* handle);
 
 /* One idle workgroup for `us` microseconds on `stream` (no reference counterpart).  The host side times pairs of these on

@@ -70,6 +70,7 @@ SIGNATURES = {
     "mmae_comm_init": (_i, [_p, _i, _i, C.POINTER(_p)]),
     "mmae_comm_allreduce_bucket": (_i, [_p, _p, _z, _i, _p]),
     "mmae_comm_broadcast": (_i, [_p, _p, _z, _i, _i, _p]),
+    "mmae_comm_info": (_i, [_p, C.POINTER(_i), C.POINTER(_i)]),
     "mmae_comm_destroy": (_i, [_p]),
     "mmae_spin_us": (_i, [_i, _p]),
 }

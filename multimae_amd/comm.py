@@ -66,6 +66,12 @@ class NativeComm:
         _lib.check(self._lib.mmae_comm_broadcast(self._handle, C.c_void_p(t.data_ptr()), t.numel(), _DTYPES[t.dtype], int(root),
                                                  C.c_void_p(st.cuda_stream)), "comm_broadcast")
 
+    def info(self):
+        """(rank, rank count) as the RCCL communicator itself reports them."""
+        r, w = C.c_int(-1), C.c_int(-1)
+        _lib.check(self._lib.mmae_comm_info(self._handle, C.byref(r), C.byref(w)), "comm_info")
+        return r.value, w.value
+
     def destroy(self):
         if self._handle is not None:
             torch.cuda.synchronize()

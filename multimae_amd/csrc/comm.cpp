@@ -28,6 +28,8 @@ struct Rccl {
     int (*CommDestroy)(Comm);
     int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t);
     int (*Broadcast)(const void*, void*, size_t, int, int, Comm, hipStream_t);
+    int (*CommCount)(Comm, int*);
+    int (*CommUserRank)(Comm, int*);
     const char* (*GetErrorString)(int);
     bool ok;
 };
@@ -81,8 +83,11 @@ int load_rccl() {
     found += resolve(lib, "ncclAllReduce", g_rccl.AllReduce);
     found += resolve(lib, "ncclBroadcast", g_rccl.Broadcast);
     found += resolve(lib, "ncclGetErrorString", g_rccl.GetErrorString);
-    if (found != 6) {
-        mmae_set_error("comm: librccl.so lacks one of ncclGetUniqueId / CommInitRank / CommDestroy / AllReduce / Broadcast / GetErrorString");
+    found += resolve(lib, "ncclCommCount", g_rccl.CommCount);
+    found += resolve(lib, "ncclCommUserRank", g_rccl.CommUserRank);
+    if (found != 8) {
+        mmae_set_error("comm: librccl.so lacks one of ncclGetUniqueId / CommInitRank / CommDestroy / AllReduce / Broadcast / "
+                       "GetErrorString / CommCount / CommUserRank");
         return MMAE_ELAUNCH;
     }
     g_rccl.ok = true;
@@ -151,6 +156,15 @@ extern "C" int mmae_comm_broadcast(void* handle, void* ptr, size_t count, int dt
     if (count == 0) return MMAE_OK;
     rc = g_rccl.Broadcast(ptr, ptr, count, dt, root, h->comm, (hipStream_t)stream);
     return rc ? fail("ncclBroadcast", rc) : MMAE_OK;
+}
+
+extern "C" int mmae_comm_info(void* handle, int* rank, int* world) {
+    if (!handle || !rank || !world) { mmae_set_error("comm_info: null pointer"); return MMAE_EINVAL; }
+    Handle* h = static_cast<Handle*>(handle);
+    int rc = g_rccl.CommCount(h->comm, world);  // what the communicator itself holds, not what the caller passed in
+    if (rc) return fail("ncclCommCount", rc);
+    rc = g_rccl.CommUserRank(h->comm, rank);
+    return rc ? fail("ncclCommUserRank", rc) : MMAE_OK;
 }
 
 extern "C" int mmae_comm_destroy(void* handle) {

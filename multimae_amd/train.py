@@ -213,12 +213,12 @@ class GradBuckets:
         (the C ABI's RCCL driver: all-reduces enqueued on the communicator's own stream, ordered against the step's
         streams by events, no host-side work objects).  MMAE_COMM=native in the environment builds one."""
         self.flat, self.group = flat, group
+        self.fallback_reason = None  # why the C ABI's communicator was not used although asked for
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.no_sync = False
         single = os.environ.get("MMAE_DP_SINGLE_RANK") == "1"
         if comm is None and os.environ.get("MMAE_COMM") == "native" and flat.params.is_cuda and (self.world > 1 or single):
-            from .comm import NativeComm
-            comm = NativeComm(group=group)
+            comm, self.group = self._native_or_fallback(group)
         self.comm = comm
         if comm is not None:
             self.world = comm.world
@@ -250,7 +250,6 @@ class GradBuckets:
             self.bucket_of[i] = len(self.buckets) - 1
         self.pending = [b[2] for b in self.buckets]
         self.signalled = [False] * len(flat.named)
-        self.works = []
         # a one-rank group still runs the collectives when asked to (MMAE_DP_SINGLE_RANK=1: exercises the RCCL path on one GPU)
         self.enabled = self.world > 1 or ((dist.is_initialized() or self.comm is not None) and single)
         # called as after_bucket(b, start, end, stream) once bucket b's gradients are final (all-reduced when there is an
@@ -258,8 +257,56 @@ class GradBuckets:
         self.after_bucket = None
         self._hooked = False
         self._comm_pending = False
+        # torch.distributed path: (bucket, work) of all-reduces whose completion nothing has been ordered after yet
+        self._unjoined = []
+        # Measurement: `timing` = None, or a list that receives (bucket, start event, end event) around every collective
+        # (the collective is then waited for on its issuing stream, so the pair brackets it; untimed steps only);
+        # `exposed` receives one (start, end) event pair per step around the wait for the last collectives in finish().
+        self.timing = None
+        self.exposed = []
         if self.enabled:
             self.install_hooks()
+
+    def _native_or_fallback(self, group):
+        """The C ABI's RCCL communicator, or, when its set-up fails on any rank, torch.distributed's own RCCL group created
+        in this process (never a re-exec: the GPU is initialised).  Returns (comm or None, group)."""
+        from . import _lib
+        from .comm import NativeComm
+        comm, err = None, ""
+        try:
+            comm = NativeComm(group=group)
+        except _lib.MmaeError as exc:
+            err = str(exc)
+        ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32)
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            if dist.get_backend(group) == "nccl":
+                ok = ok.to(self.flat.params.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)  # the ranks agree on one path
+        if int(ok.item()) == 1:
+            return comm, group
+        self.fallback_reason = err or "mmae_comm_init failed on another rank"
+        print(f"[multimae_amd] native RCCL communicator unavailable ({self.fallback_reason}); using torch.distributed's",
+              flush=True)
+        if comm is not None:
+            comm.destroy()
+        if not dist.is_initialized():
+            raise _lib.MmaeError("native communicator failed and there is no torch.distributed group to fall back to: " + err)
+        if dist.get_backend(group) != "nccl":  # the host channel is gloo: a RCCL group over the same ranks
+            ranks = dist.get_process_group_ranks(group) if group is not None else None
+            group = dist.new_group(ranks=ranks, backend="nccl", device_id=self.flat.params.device)
+        return None, group
+
+    def describe(self):
+        """What the exchange is made of, for logs and bench lines."""
+        if self.comm is not None:
+            backend, seen = "native", self.comm.info()[1]
+        elif dist.is_initialized():
+            backend, seen = "torch-" + dist.get_backend(self.group), dist.get_world_size(self.group)
+        else:
+            backend, seen = "none", 1
+        return {"backend": backend, "ranks_seen": seen, "world": self.world, "enabled": bool(self.enabled),
+                "buckets": len(self.buckets), "bucket_bytes": [4 * (e - s) for s, e, _ in self.buckets],
+                "bytes_per_step": 4 * sum(e - s for s, e, _ in self.buckets), "fallback_reason": self.fallback_reason}
 
     def install_hooks(self):
         """Per-parameter completion signals (idempotent): post-accumulate hooks for gradients delivered by autograd,
@@ -330,7 +377,13 @@ class GradBuckets:
             self.comm.stream.wait_stream(torch.cuda.current_stream(buf.device))
             if side is not None:
                 self.comm.stream.wait_stream(side)
+            if self.timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.comm.stream)
             self.comm.all_reduce_(buf)
+            if self.timing is not None:
+                e1.record(self.comm.stream)
+                self.timing.append((b, e0, e1))
             self._comm_pending = True
             if self.after_bucket is not None:
                 self.after_bucket(b, s, e, self.comm.stream)
@@ -359,17 +412,52 @@ class GradBuckets:
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
             buf.copy_(host)
             return
-        if side is None:
-            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        else:
+        # RCCL through torch.distributed: the collective runs on the process group's own stream, ordered after the stream
+        # it is issued from.  `work.wait()` makes the CURRENT stream wait for it (the host does not wait).
+        if not buf.is_cuda:
+            self._unjoined.append((b, dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+            return
+        issue = side if side is not None else torch.cuda.current_stream(buf.device)
+        if side is not None:
             side.wait_stream(torch.cuda.current_stream(buf.device))
-            with torch.cuda.stream(side):
-                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.works.append(work)
+        with torch.cuda.stream(issue):
+            if self.timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(issue)
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self.timing is not None:
+                work.wait()
+                e1.record(issue)
+                self.timing.append((b, e0, e1))
+        self._unjoined.append((b, work))
+        # With a bucket-wise consumer (the optimizer) a bucket is handed over one bucket late: by the time the next bucket
+        # is complete its all-reduce has had a bucket's worth of backward to finish under, so the stream that takes the
+        # update (the weight-gradient stream when there is one) hardly ever stalls in the wait.
+        if self.after_bucket is not None:
+            while len(self._unjoined) > 1:
+                self._hand_over(*self._unjoined.pop(0))
+
+    def _hand_over(self, b, work, final=False):
+        """Order the consumer of bucket b after its all-reduce and run it: on the weight-gradient stream while backward is
+        still going, on the current stream at the end of the step."""
+        s, e, _ = self.buckets[b]
+        dev = self.flat.grads.device
+        cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        if final or cur is None or not Fn.SIDE_STREAM_DW:
+            work.wait()
+            if self.after_bucket is not None:
+                self.after_bucket(b, s, e, cur)
+            return
+        ent = Fn._side(dev)
+        ent[0].wait_stream(cur)  # the update writes the bf16 weight copies: after every product of backward queued so far
+        with torch.cuda.stream(ent[0]):
+            work.wait()
+        self.after_bucket(b, s, e, ent[0])
+        ent[1] = True
 
     def reset(self):
         """Forget the completion signals collected so far (nothing may be in flight)."""
-        if not self.works and not self.no_sync:
+        if not self._unjoined and not self.no_sync:
             self.pending = [b[2] for b in self.buckets]
             self.signalled = [False] * len(self.signalled)
 
@@ -380,12 +468,24 @@ class GradBuckets:
         for b, left in enumerate(self.pending):
             if left > 0:
                 self._launch(b)
-        for w in self.works:
-            w.wait()
-        self.works = []
+        waiting = bool(self._unjoined) or (self.comm is not None and self._comm_pending)
+        if waiting and self.flat.grads.is_cuda:
+            # how long the step's stream sits in the wait for the last collectives: the part of the exchange that backward
+            # did not hide (the pair is read after the run; nothing here waits on the host)
+            cur = torch.cuda.current_stream(self.flat.grads.device)
+            Fn.join_side_stream(self.flat.grads.device)
+            x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            x0.record(cur)
+        for b, work in self._unjoined:
+            self._hand_over(b, work, final=True)
+        self._unjoined = []
         if self.comm is not None and self._comm_pending:
             torch.cuda.current_stream(self.flat.grads.device).wait_stream(self.comm.stream)
             self._comm_pending = False
+        if waiting and self.flat.grads.is_cuda:
+            x1.record(cur)
+            self.exposed.append((x0, x1))
+            del self.exposed[:-256]
         self.pending = [b[2] for b in self.buckets]
         self.signalled = [False] * len(self.signalled)
 
@@ -534,13 +634,17 @@ class PretrainStep:
         # The optimizer is bandwidth-bound work at the end of a step of matrix products.  Without clipping / skipping (which
         # need the norm of the whole gradient first; the reference's default, pretrain_argparser.py:47-50) a bucket of
         # parameters can be updated as soon as its gradients are final, beside the rest of backward: on the weight-gradient
-        # stream with one rank, on the communicator's stream behind the bucket's all-reduce with the C ABI's RCCL driver.
-        # (torch.distributed's collectives run on a stream of its own that nothing else can be queued on; waiting for it from
-        # a compute stream would stall that stream, so there the update stays at the end of the step.)
+        # stream with one rank, on the communicator's stream behind the bucket's all-reduce with the C ABI's RCCL driver, and
+        # with torch.distributed's RCCL group on the weight-gradient stream one bucket late (GradBuckets._hand_over: the
+        # group's collectives run on a stream of its own that nothing else can be queued on, so the update waits for it from
+        # another stream, at a moment when the all-reduce has normally finished).  gloo (host-staged, rehearsal) keeps the
+        # update at the end of the step.
         if eager_optimizer is None:
             eager_optimizer = os.environ.get("MMAE_EAGER_OPT", "1") != "0"
+        staged = (self.buckets.enabled and self.buckets.comm is None and dist.is_initialized()
+                  and dist.get_backend(self.buckets.group) != "nccl")
         self.eager = bool(eager_optimizer and clip_grad is None and skip_grad is None and self.flat.params.is_cuda
-                          and (not self.buckets.enabled or self.buckets.comm is not None))
+                          and not staged)
         if self.eager:
             self._tr_tables = [self.flat.transpose_table_for(s, e) for s, e, _ in self.buckets.buckets]
             self.buckets.install_hooks()

@@ -39,7 +39,27 @@ def test_bench_stdout_is_the_json_line_alone_when_a_process_group_starts():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout[:2000]
-    assert json.loads(lines[0])["n_gpus"] == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1
+    # the exchange describes itself: backend, the communicator's own rank count, buckets and bytes, the un-hidden wait
+    c = j["comm"]
+    assert c["backend"] == "torch-nccl" and c["ranks_seen"] == 1 and c["requested"] == "torch" and c["fallback_reason"] is None
+    assert c["buckets"] == len(c["bucket_bytes"]) > 3 and c["bytes_per_step"] == sum(c["bucket_bytes"]) > 3.5e8
+    assert c["eager_optimizer"] is True and c["exposed_ms_per_step"] >= 0.0
+    assert "gradient exchange: torch-nccl over 1 rank(s)" in out.stderr
+
+
+@pytest.mark.gpu
+def test_bench_comm_flag_selects_the_native_communicator_and_times_its_collectives():
+    env = dict(os.environ, MMAE_DP_SINGLE_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--comm", "native"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[:2000]
+    c = json.loads(lines[0])["comm"]
+    assert c["backend"] == "native" and c["requested"] == "native" and c["ranks_seen"] == 1 and c["eager_optimizer"] is True
+    assert len(c["allreduce_ms_per_bucket"]) == c["buckets"] and c["allreduce_ms_per_step"] > 0.0
 
 
 def test_pmc_traffic_lookup_reads_the_committed_table():

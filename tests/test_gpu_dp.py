@@ -115,7 +115,32 @@ def _rccl_worker(rank, port, out):
     t = torch.tensor([1.5], device="cuda", dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     torch.cuda.synchronize()
-    torch.save({"params": step.flat.params.cpu(), "gn2": gn2.cpu(), "loss": loss.cpu(), "t": t.cpu()}, out)
+    info = step.buckets.describe()
+    assert info["backend"] == "torch-nccl" and info["ranks_seen"] == 1 and info["buckets"] == len(step.buckets.buckets)
+    assert info["bytes_per_step"] == 4 * sum(e - s for s, e, _ in step.buckets.buckets) and info["fallback_reason"] is None
+    assert len(step.buckets.exposed) == 2  # one (start, end) pair per step around the final wait
+    # the same two steps without clipping: the optimizer then runs bucket by bucket, each bucket one behind its all-reduce
+    # (on the weight-gradient stream), and must land on the parameters of the plain end-of-step update
+    def two_steps(eager):
+        m2 = _build(cfg)
+        m2.load_state_dict(G.perturbed_state(cfg, seed=7))
+        m2.cuda()
+        st = PretrainStep(m2, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05, bucket_mb=0.25, eager_optimizer=eager)
+        assert st.eager is eager and st.buckets.enabled
+        for _ in range(2):
+            st(x, mask_randomness=rnd)
+        torch.cuda.synchronize()
+        return st
+    eager, plain = two_steps(True), two_steps(False)
+    eager_params = eager.flat.params.cpu()
+    eager.buckets.timing = []
+    eager(x, mask_randomness=rnd)
+    torch.cuda.synchronize()
+    spans = [(b, a.elapsed_time(c)) for b, a, c in eager.buckets.timing]
+    eager.buckets.timing = None
+    torch.save({"params": step.flat.params.cpu(), "gn2": gn2.cpu(), "loss": loss.cpu(), "t": t.cpu(),
+                "eager": eager_params, "plain": plain.flat.params.cpu(), "spans": spans,
+                "n_buckets": len(eager.buckets.buckets)}, out)
     # a further step with the model's own mask draws under torch's synchronisation check: the bucketed all-reduces, their
     # waits and the optimizer's join must not make the host wait for the device
     step(x)
@@ -163,9 +188,12 @@ def test_rccl_bucket_path_with_a_one_rank_group(tmp_path):
     got = torch.load(out)
     step, loss, gn2 = _single_rank_reference()
     assert float(got["t"]) == 1.5
+    assert sorted(b for b, _ in got["spans"]) == list(range(got["n_buckets"])) and all(ms >= 0 for _, ms in got["spans"])
     assert torch.equal(got["loss"], loss.cpu())
     assert torch.equal(got["gn2"], gn2.cpu())
     assert torch.equal(got["params"], step.flat.params.cpu())
+    # bucket-wise optimizer behind the RCCL group's all-reduces: the same element-wise arithmetic as the one-launch update
+    assert torch.equal(got["eager"], got["plain"]), (got["eager"] - got["plain"]).abs().max()
 
 
 def test_native_rccl_driver_with_a_one_rank_communicator(tmp_path):
