@@ -10,7 +10,7 @@ FLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-variable 
 
 all: $(LIB)
 
-$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/mmae.h
+$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/ln_rows.h include/mmae.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 

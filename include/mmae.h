@@ -49,6 +49,15 @@ int mmae_version(void);
 int mmae_gemm_nt(int epi, const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,
                  void* out, long ldo, void* out2, const void* aux, long ldaux, mmae_stream_t stream);
 
+/* The residual product of a transformer block fused with the LayerNorm that follows it (multimae/multimae_utils.py:283-284:
+ * x = x + proj(attn) ... norm2(x); x = x + fc2(...) ... the next block's norm1): out(f32) [M,N] = aux + A W^T + bias (rows of
+ * out are N apart), then ln(bf16) [M,N] = LayerNorm(out) * gamma + beta, mean / rstd [M].  The same kernels as mmae_gemm_nt(epi
+ * 2) followed by mmae_layernorm_fwd and bitwise the same results; where the product ends in a tail launch that leaves CUs
+ * idle, those CUs normalise the already complete rows while the tail runs.  N <= 1024. */
+int mmae_gemm_nt_resid_ln(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias, float* out,
+                          const float* aux, long ldaux, const float* gamma, const float* beta, float eps, void* ln_bf16,
+                          float* mean, float* rstd, mmae_stream_t stream);
+
 /* Kernel choice for mmae_gemm_nt and its two siblings below: 0 = by problem size (default), 1 = always the 128x128
  * two-workgroups-per-CU kernel, 4 = persistent 128x128 (2-stage ring), 5 = 256x256 eight-wave ping-pong kernel (K a
  * multiple of 128, else as 0), 7 = 128x256 four-wave kernel, two workgroups per CU (K a multiple of 64, else as 0).  Like every *_set_* switch of this library it applies to the calling thread's later

@@ -15,6 +15,7 @@ SIGNATURES = {
     "mmae_last_error": (C.c_char_p, []),
     "mmae_version": (_i, []),
     "mmae_gemm_nt": (_i, [_i, _p, _l, _p, _l, _i, _i, _i, _p, _p, _l, _p, _p, _l, _p]),
+    "mmae_gemm_nt_resid_ln": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _p, _l, _p, _p, _f, _p, _p, _p, _p]),
     "mmae_gemm_tn_set_variant": (None, [_i]),
     "mmae_gemm_nt_set_half_tiles": (None, [_i]),
     "mmae_gemm_nt_set_phase": (None, [_i]),

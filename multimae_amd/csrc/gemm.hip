@@ -6,8 +6,12 @@
 // Both use 128x128 output tiles, four waves (2x2, 64x64 each), v_mfma_f32_16x16x32_bf16,
 // 16-byte global->LDS DMA into a double-buffered, XOR-swizzled LDS image.
 #include "common.h"
+#include "ln_rows.h"
 #include <type_traits>
 #include <stdlib.h>
+#ifndef MMAE_LN_TAIL_R
+#define MMAE_LN_TAIL_R 8  // rows per wave and pass of the LayerNorm workgroups beside a tail launch (eight waves per CU)
+#endif
 #ifndef MMAE_RES_AHEAD
 #define MMAE_RES_AHEAD 3  // pieces of the residual fetched ahead of the stores in the row-major epilogue (tuning builds override it)
 #endif
@@ -42,6 +46,10 @@ struct GemmNT {
     const int* add_idx; const float* add_tab;
     int C, P, NH, NW, out_f32;  // EPI_UNPATCH
 };
+
+// LayerNorm rows handed to workgroups that would otherwise idle beside the tail tiles of a residual GEMM (gemm_nt_pp_kernel):
+// x f32 [rows, dim] (rows the preceding full-tile launch has already written) -> y bf16, mean, rstd.  rows == 0: no job.
+struct LnJob { const float* x; const float* gamma; const float* beta; bf16* y; float* mean; float* rstd; int rows, dim; float eps; };
 
 // Stores one wave's 64x64 accumulator block: (acc[2u][mi], acc[2u+1][mi]) = C[m = mw + mi*16 + fr][n = nw + 32*u + 8*fq + 0..7]
 // bias_regs (optional): the lane's 16 bias values, [8*u + e] = bias[nw + 32*u + 8*fq + e], for callers that cannot afford a
@@ -622,15 +630,27 @@ extern "C" int mmae_debug_pp_trace(void* host_out) {
 #define PP_TRACE(slot) do {} while (0)
 #endif
 template <int EPI, int TM>
-__global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_m, int tiles_n, int gemm_blocks, LnJob job) {
     constexpr bool HALF = TM < 256;      // 128- and 64-row tiles: two phases per k-tile, one accumulator block per wave
     constexpr bool QUARTER = TM == 64;   // 64-row tiles: the wave's block is 32 x 64 (two activation fragments)
     constexpr int NMI = QUARTER ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) char ppsmem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Workgroups past the GEMM's own (tail launches of the residual epilogue only): a tail of 64-row tiles occupies two
+    // thirds of the CUs (N = 768 at 25344 rows: 168 of 256), and every workgroup of this kernel owns a CU through its LDS
+    // reservation, so the rest of the grid lands on the idle CUs and normalises rows that the full-tile launch before
+    // this one has already written (the LayerNorm that follows the product in the block), eight waves per CU.
+    if constexpr (EPI == EPI_RESID && HALF) {
+        if ((int)blockIdx.x >= gemm_blocks) {
+            const int first = ((int)blockIdx.x - gemm_blocks) * 8 + wave, nwaves = ((int)gridDim.x - gemm_blocks) * 8;
+            if (job.dim == 768) ln_fwd_rows<3, MMAE_LN_TAIL_R>(job.x, job.gamma, job.beta, job.y, job.mean, job.rstd, job.rows, job.eps, first * MMAE_LN_TAIL_R, nwaves * MMAE_LN_TAIL_R, lane);
+            else if (job.dim == 1024) ln_fwd_rows<4, MMAE_LN_TAIL_R * 3 / 4>(job.x, job.gamma, job.beta, job.y, job.mean, job.rstd, job.rows, job.eps, first * (MMAE_LN_TAIL_R * 3 / 4), nwaves * (MMAE_LN_TAIL_R * 3 / 4), lane);
+            return;
+        }
+    }
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fq = lane >> 4, swz = fr >> 1;
-    const int ntiles = tiles_m * tiles_n, G = gridDim.x;
+    const int ntiles = tiles_m * tiles_n, G = gemm_blocks;
     const int me = xcd_remap(blockIdx.x, G);
     const int nk = p.K >> 6;
     if (me >= ntiles) return;
@@ -939,7 +959,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmNT p, int tiles_
 }
 
 template <int EPI>
-static int launch_nt_pp(const GemmNT& p, hipStream_t s);
+static int launch_nt_pp(const GemmNT& p, hipStream_t s, const LnJob* ln = nullptr, int* ln_rows_done = nullptr);
 // For timing the two launches of the ping-pong path separately: 0 = both (default), 1 = the full-tile launch only,
 // 2 = the half-tile launch only.  g_nt_full_rows: rows covered by full tiles in this thread's last gemm_nt call.
 static thread_local int g_nt_phase = 0, g_nt_full_rows = 0, g_nt_tail_rows = 0;
@@ -1017,8 +1037,11 @@ static int launch_nt_persist(const GemmNT& p, hipStream_t s) {
     return MMAE_OK;
 }
 
+// ln / ln_rows_done (residual epilogue): the LayerNorm of the product's output.  When the plan has a tail launch that leaves
+// CUs idle, the rows the full-tile launch covers (or as many of them as the idle CUs get through while the tail runs) are
+// normalised by extra workgroups of the tail launch; *ln_rows_done = the number of leading rows taken care of (0: none).
 template <int EPI>
-static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
+static int launch_nt_pp(const GemmNT& p, hipStream_t s, const LnJob* ln, int* ln_rows_done) {
     static bool reserved = false;
     if (!reserved) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
@@ -1042,9 +1065,10 @@ static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
         if (pl.halves) q.M = pl.full_panels * 256;
         int grid = pl.full_panels * pl.tiles_n;
         if (grid > num_cus()) grid = num_cus();
-        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, 256>), dim3(grid), dim3(512), PP_LDS, s, q, pl.full_panels, pl.tiles_n);
+        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, 256>), dim3(grid), dim3(512), PP_LDS, s, q, pl.full_panels, pl.tiles_n, grid, LnJob{});
         MMAE_CHECK_LAUNCH("gemm_nt_pp");
     }
+    if (ln_rows_done) *ln_rows_done = 0;
     if (pl.halves && g_nt_phase != 1) {
         // the rows after the full panels, as a problem of its own
         const long r0 = (long)pl.full_panels * 256;
@@ -1058,10 +1082,34 @@ static int launch_nt_pp(const GemmNT& p, hipStream_t s) {
         if (p.aux) q.aux = (const char*)p.aux + r0 * p.ldaux * aux_sz;
         int grid = pl.halves;
         if (grid > num_cus()) grid = num_cus();
+        int total = grid;
+        LnJob job = {};
+        if constexpr (EPI == EPI_RESID) {
+            // idle CUs beside the tail: they normalise leading rows of the output (complete since the full-tile launch).
+            // One CU streams about 26 GB/s whatever is in flight, so the 88 idle CUs of the N = 768 tail get through about
+            // half of the 21760 complete rows while the tail runs (scripts/bench_lnfuse.py: with every row the launch
+            // grows by 12 us, with half by 5); the LayerNorm launch that follows takes the rest.
+            static double env_share = -1.0;
+            if (env_share < 0.0) {
+                const char* e = getenv("MMAE_LN_TAIL_SHARE");
+                env_share = e ? atof(e) : 0.5;
+            }
+            const int idle = num_cus() - grid;
+            if (ln && ln->rows > 0 && idle >= 32 && g_nt_phase == 0 && env_share > 0.0 && (ln->dim == 768 || ln->dim == 1024)) {
+                job = *ln;
+                long rows = (long)(env_share * (double)r0);
+                rows = rows < r0 ? rows : r0;
+                job.rows = (int)(rows / 8 * 8);
+                if (job.rows > 0) {
+                    total = num_cus();
+                    if (ln_rows_done) *ln_rows_done = job.rows;
+                }
+            }
+        }
         if (pl.tail_rows == 64)
-            hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, 64>), dim3(grid), dim3(512), PP_LDS, s, q, (q.M + 63) / 64, pl.tiles_n);
+            hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, 64>), dim3(total), dim3(512), PP_LDS, s, q, (q.M + 63) / 64, pl.tiles_n, grid, job);
         else
-            hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, 128>), dim3(grid), dim3(512), PP_LDS, s, q, (q.M + 127) / 128, pl.tiles_n);
+            hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, 128>), dim3(total), dim3(512), PP_LDS, s, q, (q.M + 127) / 128, pl.tiles_n, grid, job);
         MMAE_CHECK_LAUNCH("gemm_nt_pp(half tiles)");
     }
     return MMAE_OK;
@@ -1362,7 +1410,8 @@ extern "C" int mmae_gemm_nt_last_full_rows(void) { return g_nt_full_rows; }
 extern "C" int mmae_gemm_nt_last_tail_rows(void) { return g_nt_tail_rows; }
 
 template <int EPI>
-static int launch_nt(const GemmNT& p, hipStream_t s) {
+static int launch_nt(const GemmNT& p, hipStream_t s, const LnJob* ln = nullptr, int* ln_rows_done = nullptr) {
+    if (ln_rows_done) *ln_rows_done = 0;
     // Measured on MI355X at the shapes of the ViT-B step.  The 256x256 ping-pong kernel runs a k-tile in about 60 % of the
     // time the 128x128 kernels need per FLOP, but a workgroup owns a whole CU, so it pays only where the tile count
     // fills the rounds of CUs, counting a tail of half tiles at its cost (N = 2304 / 3072 at M = 25344: 93 %, the decoder
@@ -1370,7 +1419,7 @@ static int launch_nt(const GemmNT& p, hipStream_t s) {
     // 128x128 kernels the persistent ring wins for many tiles of a short K loop (N >= 2048), the plain grid elsewhere.
     const long tiles128 = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     g_nt_full_rows = p.M;
-    if (g_nt_variant == 5 && p.K % 128 == 0) { g_last_nt = 5; return launch_nt_pp<EPI>(p, s); }
+    if (g_nt_variant == 5 && p.K % 128 == 0) { g_last_nt = 5; return launch_nt_pp<EPI>(p, s, ln, ln_rows_done); }
     if constexpr (EPI != EPI_TOKENS && EPI != EPI_UNPATCH) {
         if (g_nt_variant == 7 && p.K % 64 == 0 && p.K >= 128) { g_last_nt = 7; return launch_nt_p2<EPI>(p, s); }
     }
@@ -1399,7 +1448,7 @@ static int launch_nt(const GemmNT& p, hipStream_t s) {
         // (M = 25344: N = 768, K = 768, fill 0.66: 57 against 64 us with the residual epilogue, 38 against 42 us without;
         // N = 256, K = 768, fill 0.39: 15 against 17 us)
         const double min_fill = env_fill > 0.0 ? env_fill : 0.35;
-        if (fill >= min_fill) { g_last_nt = 5; return launch_nt_pp<EPI>(p, s); }
+        if (fill >= min_fill) { g_last_nt = 5; return launch_nt_pp<EPI>(p, s, ln, ln_rows_done); }
     }
     if (g_nt_variant == 4 || (g_nt_variant == 0 && p.N >= 2048 && tiles128 >= 4 * 2 * num_cus())) {
         g_last_nt = 4;
@@ -1450,6 +1499,31 @@ extern "C" int mmae_gemm_nt(int epi, const void* A, long lda, const void* W, lon
     }
     mmae_set_error("gemm_nt: unknown epilogue %d", epi);
     return MMAE_EINVAL;
+}
+
+// out(f32) = aux + A W^T + bias, then ln(bf16) = LayerNorm(out) with its row statistics: the residual product of a block and the
+// LayerNorm that follows it (multimae/multimae_utils.py:283-284 of the reference: x = x + attn(...); ... norm2(x), and the
+// next block's norm1 after fc2).  Same kernels as mmae_gemm_nt(epi 2) + mmae_layernorm_fwd, bitwise the same results; where the
+// product ends in a tail launch that leaves CUs idle, those CUs normalise the rows that are already complete meanwhile.
+extern "C" int mmae_gemm_nt_resid_ln(const void* A, long lda, const void* W, long ldw, int M, int N, int K, const float* bias,
+                                     float* out, const float* aux, long ldaux, const float* gamma, const float* beta, float eps,
+                                     void* ln_bf16, float* mean, float* rstd, hipStream_t stream) {
+    int rc = check_nt(A, lda, W, ldw, M, N, K, out);
+    if (rc) return rc;
+    MMAE_REQUIRE(aux && ldaux >= N && gamma && beta && ln_bf16 && mean && rstd, MMAE_EINVAL, "gemm_nt_resid_ln: null pointer");
+    MMAE_REQUIRE(N % 4 == 0 && N <= 1024, MMAE_ESHAPE, "gemm_nt_resid_ln: N=%d must be a multiple of 4 and <= 1024 (one LayerNorm row)", N);
+    MMAE_REQUIRE((uintptr_t)out % 16 == 0 && (uintptr_t)aux % 16 == 0 && ldaux % 8 == 0 && (!bias || (uintptr_t)bias % 16 == 0),
+                 MMAE_EINVAL, "gemm_nt_resid_ln: out / aux / bias must be 16-byte aligned (aux row stride a multiple of 8)");
+    GemmNT p = {};
+    p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
+    p.bias = bias; p.out = out; p.ldo = N; p.aux = aux; p.ldaux = ldaux;
+    const LnJob job = {out, gamma, beta, (bf16*)ln_bf16, mean, rstd, M, N, eps};
+    int done = 0;
+    rc = launch_nt<EPI_RESID>(p, stream, &job, &done);
+    if (rc) return rc;
+    if (done >= M) return MMAE_OK;
+    return mmae_ln_fwd_launch(out + (long)done * N, gamma, beta, (bf16*)ln_bf16 + (long)done * N, mean + done, rstd + done, M - done, N,
+                              eps, stream);
 }
 
 extern "C" int mmae_patch_embed_gemm(const void* A, const void* W, int M, int N, int K, const int* add_idx,

@@ -1,6 +1,7 @@
 // LayerNorm forward / backward for the fp32 residual stream (gfx950). One wave per row, the row held
 // in registers; HBM-bound: forward moves 4*dim (read) + 2*dim (bf16 write) bytes per row.
 #include "common.h"
+#include "ln_rows.h"
 #include <stdlib.h>
 
 #define LN_MAXV 4  // float4 per lane: dim <= 64 * 4 * LN_MAXV = 1024
@@ -49,71 +50,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
 }
 
-// Forward for dim == 256 * NV, R rows per wave and pass, persistent waves: as in the backward below, every load of the R
-// rows is issued before the first of the two wave reductions (the second needs the first: mean, then variance around it),
-// so the reductions of one pass overlap with the loads of the rows in flight instead of serialising one row's round trip
-// per wave; gamma and beta stay in registers across rows.
+// Forward for dim == 256 * NV, R rows per wave and pass, persistent waves (the row loop is ln_fwd_rows, ln_rows.h).
 template <int NV, int R>
 __global__ __launch_bounds__(256) void layernorm_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, bf16* __restrict__ y,
                                                                  float* __restrict__ mean, float* __restrict__ rstd, int rows,
                                                                  float eps) {
-    constexpr int dim = 256 * NV;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    f32x4 gm[NV], bt[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        gm[i] = ((const f32x4*)gamma)[lane + i * 64];
-        bt[i] = ((const f32x4*)beta)[lane + i * 64];
-    }
-    const int stride = gridDim.x * 4 * R;
-    for (int row0 = (blockIdx.x * 4 + w) * R; row0 < rows; row0 += stride) {
-        f32x4 v[R][NV];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int row = row0 + r < rows ? row0 + r : rows - 1;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) v[r][i] = ((const f32x4*)(x + (long)row * dim))[lane + i * 64];
-        }
-        float s[R], q[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            s[r] = 0.f;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) s[r] += v[r][i][0] + v[r][i][1] + v[r][i][2] + v[r][i][3];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int r = 0; r < R; ++r) s[r] += __shfl_xor(s[r], o, 64);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            s[r] = s[r] / dim;  // the mean
-            q[r] = 0.f;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                v[r][i] = v[r][i] - s[r];
-                q[r] += v[r][i][0] * v[r][i][0] + v[r][i][1] * v[r][i][1] + v[r][i][2] * v[r][i][2] + v[r][i][3] * v[r][i][3];
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int r = 0; r < R; ++r) q[r] += __shfl_xor(q[r], o, 64);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (row0 + r >= rows) break;
-            const float rs = rsqrtf(q[r] / dim + eps);
-            if (lane == 0) { mean[row0 + r] = s[r]; rstd[row0 + r] = rs; }
-            bf16* yr = y + (long)(row0 + r) * dim;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const f32x4 o = v[r][i] * rs * gm[i] + bt[i];
-                bf16x4 ob = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
-                *(bf16x4*)(yr + (lane + i * 64) * 4) = ob;
-            }
-        }
-    }
+    ln_fwd_rows<NV, R>(x, gamma, beta, y, mean, rstd, rows, eps, (blockIdx.x * 4 + w) * R, gridDim.x * 4 * R, lane);
 }
 
 // Backward. Each wave walks rows `wave_global, wave_global + total_waves, ...`, keeps its dgamma / dbeta
@@ -342,6 +286,11 @@ extern "C" int mmae_layernorm_fwd(const float* x, const float* gamma, const floa
     MMAE_REQUIRE(x && gamma && beta && y && mean && rstd, MMAE_EINVAL, "layernorm_fwd: null pointer");
     MMAE_REQUIRE(rows > 0 && dim > 0 && dim % 4 == 0 && dim <= 256 * LN_MAXV, MMAE_ESHAPE,
                  "layernorm_fwd: dim=%d must be a multiple of 4 and <= %d", dim, 256 * LN_MAXV);
+    return mmae_ln_fwd_launch(x, gamma, beta, y, mean, rstd, rows, dim, eps, stream);
+}
+
+int mmae_ln_fwd_launch(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows, int dim,
+                       float eps, hipStream_t stream) {
     static int env_rows = -1;  // tuning: MMAE_LN_FWD_ROWS = rows per wave and pass of the multi-row kernel (0 = the one-row kernel)
     if (env_rows < 0) {
         const char* e = getenv("MMAE_LN_FWD_ROWS");

@@ -283,14 +283,22 @@ def _ln_bwd(dy, x, n_w, n_b, mean, rstd, dres=None, shadow=False):
 # ---------------------------------------------------------------------------------------------
 # pieces shared by the encoder block, the decoder blocks and the decoder head
 # ---------------------------------------------------------------------------------------------
-def _mlp_fwd(x, n_w, n_b, fc1_w, fc1_b, fc2_w, fc2_b, eps=1e-6):
-    """x f32 [M,D] -> x + fc2(gelu(fc1(LN(x)))) and the tensors the backward needs."""
-    ln, mean, rstd = ops.layernorm_fwd(x, n_w, n_b, eps)
+def _mlp_fwd(x, n_w, n_b, fc1_w, fc1_b, fc2_w, fc2_b, eps=1e-6, pre_ln=None, next_norm=None):
+    """x f32 [M,D] -> x + fc2(gelu(fc1(LN(x)))) and the tensors the backward needs.  pre_ln = (LN(x) bf16, mean, rstd) when
+    the product that made x already normalised it (ops.gemm_nt_resid_ln)."""
+    ln, mean, rstd = pre_ln if pre_ln is not None else ops.layernorm_fwd(x, n_w, n_b, eps)
     w1, w1t = bf16_weights(fc1_w)
     w2, w2t = bf16_weights(fc2_w)
     h, act = ops.gemm_nt(ops.EPI_GELU, ln, w1, fc1_b)
+    saved = (x, ln, mean, rstd, h, act, w1t, w2t, (n_w, n_b, fc1_w, fc1_b, fc2_w, fc2_b))
+    if next_norm is not None:  # callers that pass it take three results
+        D = x.shape[-1]
+        if D <= 1024 and D % 256 == 0:
+            y, ln_n, mean_n, rstd_n = ops.gemm_nt_resid_ln(act, w2, fc2_b, x, next_norm[0], next_norm[1], next_norm[2])
+            return y, saved, (ln_n, mean_n, rstd_n)
+        return ops.gemm_nt(ops.EPI_RESID, act, w2, fc2_b, aux=x), saved, None
     y = ops.gemm_nt(ops.EPI_RESID, act, w2, fc2_b, aux=x)
-    return y, (x, ln, mean, rstd, h, act, w1t, w2t, (n_w, n_b, fc1_w, fc1_b, fc2_w, fc2_b))
+    return y, saved
 
 
 def _mlp_bwd(g, saved):
@@ -305,16 +313,22 @@ def _mlp_bwd(g, saved):
     return dx, [dnw, dnb, dw1, db1, dw2, db2]
 
 
-def _self_attn_fwd(x, B, N, heads, n_w, n_b, qkv_w, qkv_b, proj_w, proj_b, eps=1e-6):
+def _self_attn_fwd(x, B, N, heads, n_w, n_b, qkv_w, qkv_b, proj_w, proj_b, eps=1e-6, next_norm=None, pre_ln=None):
+    """next_norm = (gamma, beta, eps) of the LayerNorm that reads this half's output (the block's norm2): the residual product
+    then also returns (LN(y) bf16, mean, rstd) as a third result (None without it)."""
     D = x.shape[-1]
     d = D // heads
-    ln, mean, rstd = ops.layernorm_fwd(x, n_w, n_b, eps)
+    ln, mean, rstd = pre_ln if pre_ln is not None else ops.layernorm_fwd(x, n_w, n_b, eps)
     wq, wqt = bf16_weights(qkv_w)
     wp, wpt = bf16_weights(proj_w)
     qkv = ops.gemm_nt(ops.EPI_BF16, ln, wq, qkv_b)
     o, lse = ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, heads, N, N, d, d ** -0.5)
+    saved = (x, ln, mean, rstd, qkv, o, lse, wqt, wpt, (n_w, n_b, qkv_w, qkv_b, proj_w, proj_b), B, N, heads)
+    if next_norm is not None and D <= 1024 and D % 256 == 0:
+        y, ln2, mean2, rstd2 = ops.gemm_nt_resid_ln(o, wp, proj_b, x, next_norm[0], next_norm[1], next_norm[2])
+        return y, saved, (ln2, mean2, rstd2)
     y = ops.gemm_nt(ops.EPI_RESID, o, wp, proj_b, aux=x)
-    return y, (x, ln, mean, rstd, qkv, o, lse, wqt, wpt, (n_w, n_b, qkv_w, qkv_b, proj_w, proj_b), B, N, heads)
+    return y, saved, None
 
 
 def _self_attn_bwd(g, saved):
@@ -338,11 +352,21 @@ class BlockFn(torch.autograd.Function):
     eps of the two LayerNorms."""
 
     @staticmethod
-    def forward(ctx, x, heads, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, eps1=1e-6, eps2=1e-6):
+    def forward(ctx, x, heads, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, eps1=1e-6, eps2=1e-6, chain=None):
+        """chain (run_blocks): a dict that carries the first LayerNorm of a block from the block before it, whose last
+        product computes it: chain["pre"] = (norm1(x) bf16, mean, rstd) of THIS block's input when present (consumed here);
+        chain["next"] = (gamma, beta, eps) of the next block's norm1, for which this block leaves chain["pre"]."""
         B, N, D = x.shape
         x2 = x.contiguous().reshape(B * N, D)
-        x1, s_att = _self_attn_fwd(x2, B, N, heads, n1w, n1b, qkvw, qkvb, pw, pb, eps1)
-        y, s_mlp = _mlp_fwd(x1, n2w, n2b, f1w, f1b, f2w, f2b, eps2)
+        pre = chain.pop("pre", None) if chain is not None else None
+        nxt = chain.get("next") if chain is not None else None
+        x1, s_att, ln2 = _self_attn_fwd(x2, B, N, heads, n1w, n1b, qkvw, qkvb, pw, pb, eps1, next_norm=(n2w, n2b, eps2), pre_ln=pre)
+        if nxt is not None:
+            y, s_mlp, ln_next = _mlp_fwd(x1, n2w, n2b, f1w, f1b, f2w, f2b, eps2, pre_ln=ln2, next_norm=nxt)
+        else:
+            (y, s_mlp), ln_next = _mlp_fwd(x1, n2w, n2b, f1w, f1b, f2w, f2b, eps2, pre_ln=ln2), None
+        if ln_next is not None:
+            chain["pre"] = ln_next
         ctx.saved = (s_att, s_mlp)
         ctx.shape = (B, N, D)
         return y.reshape(B, N, D)
@@ -354,7 +378,28 @@ class BlockFn(torch.autograd.Function):
         ctx.saved = None
         g1, gm = _mlp_bwd(g.contiguous().reshape(B * N, D), s_mlp)
         g0, ga = _self_attn_bwd(g1, s_att)
-        return (g0.reshape(B, N, D), None, *ga, *gm, None, None)
+        return (g0.reshape(B, N, D), None, *ga, *gm, None, None, None)
+
+
+def run_blocks(blocks, x):
+    """x through a sequence of multimae_utils.Block modules (the encoder).  Blocks that run as the fused node hand the first
+    LayerNorm of the next block to their own last product (ops.gemm_nt_resid_ln: idle CUs of that product's tail launch
+    normalise the rows that are complete); results are bitwise those of calling the blocks one after the other."""
+    blocks = list(blocks)
+    chain = {}
+    for i, blk in enumerate(blocks):
+        nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+        fused = getattr(blk, "fused_node", None)
+        if fused is None or not fused():
+            chain.clear()
+            x = blk(x)
+            continue
+        chain.pop("next", None)
+        nfused = getattr(nxt, "fused_node", None) if nxt is not None else None
+        if nfused is not None and nfused() and x.is_cuda:
+            chain["next"] = (nxt.norm1.weight.detach(), nxt.norm1.bias.detach(), nxt.norm1.eps)
+        x = blk(x, chain=chain)
+    return x
 
 
 # ---------------------------------------------------------------------------------------------

@@ -213,7 +213,7 @@ class MultiMAE(nn.Module):
                                   self.global_tokens, len(domains), *[x[d] for d in domains], *[ad.proj.weight for ad in adapters],
                                   *[ad.proj.bias for ad in adapters], *[ad.class_table for ad in adapters],
                                   *[ad.learnable_pos_table(t) for ad, t in zip(adapters, tables)])
-        encoder_tokens = self.encoder(tokens)
+        encoder_tokens = Fn.run_blocks(self.encoder, tokens)
         if self.output_adapters is None:
             return encoder_tokens, task_masks
         # Adapters listed in fp32_output_adapters (reference: multimae/multimae.py:426-436 runs them outside autocast)

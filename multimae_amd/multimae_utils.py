@@ -162,14 +162,21 @@ class Block(nn.Module):
         self._ln_kernel = all(isinstance(n, nn.LayerNorm) and n.elementwise_affine and n.bias is not None
                               and tuple(n.normalized_shape) == (dim,) for n in (self.norm1, self.norm2))
 
-    def forward(self, x):
+    def fused_node(self) -> bool:
+        """True when forward() runs as the one fused autograd node (the pretraining configuration)."""
+        a, m = self.attn, self.mlp
+        return bool(self._ln_kernel and m.act is None
+                    and not (self.training and (a.attn_drop or a.proj_drop or m.drop or isinstance(self.drop_path, DropPath))))
+
+    def forward(self, x, chain=None):
+        """chain: see functional.run_blocks (the encoder hands each block's first LayerNorm to the block before it)."""
         a, m = self.attn, self.mlp
         if not self._ln_kernel:
             x = x + self.drop_path(a(self.norm1(x)))
             return x + self.drop_path(m(self.norm2(x)))
-        if m.act is not None or (self.training and (a.attn_drop or a.proj_drop or m.drop or isinstance(self.drop_path, DropPath))):
+        if not self.fused_node():
             x = x + self.drop_path(a(layer_norm(self.norm1, x)))
             return x + self.drop_path(m(layer_norm(self.norm2, x)))
         return Fn.BlockFn.apply(x, a.num_heads, self.norm1.weight, self.norm1.bias, a.qkv.weight, _bias_or_zeros(a.qkv),
                                 a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias,
-                                m.fc2.weight, m.fc2.bias, self.norm1.eps, self.norm2.eps)
+                                m.fc2.weight, m.fc2.bias, self.norm1.eps, self.norm2.eps, chain)

@@ -148,6 +148,35 @@ def gemm_nt(epi: int, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Ten
     return (out, out2) if epi == EPI_GELU else out
 
 
+def gemm_nt_resid_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], aux: torch.Tensor, gamma: torch.Tensor,
+                     beta: torch.Tensor, eps: float = 1e-6):
+    """out f32 [M,N] = aux + a @ w^T + bias, then LayerNorm(out): returns (out, ln bf16 [M,N], mean [M], rstd [M]).
+    gemm_nt(EPI_RESID) followed by layernorm_fwd, bitwise; one C-ABI call so that CUs the product's tail launch leaves idle
+    normalise the rows that are already complete."""
+    if PROFILE is not None:  # per-kernel timing: the two kernels on their own
+        out = gemm_nt(EPI_RESID, a, w, bias, aux=aux)
+        ln, mean, rstd = layernorm_fwd(out, gamma, beta, eps)
+        return out, ln, mean, rstd
+    _req(a, BF16, "gemm_nt_resid_ln a", contiguous=False)
+    _req(w, BF16, "gemm_nt_resid_ln w", contiguous=False)
+    M, K, lda = _rows2d(a, "gemm_nt_resid_ln a")
+    N, K2, ldw = _rows2d(w, "gemm_nt_resid_ln w")
+    if K != K2:
+        raise _lib.MmaeError(f"gemm_nt_resid_ln: inner dims differ ({K} vs {K2})")
+    _req(aux, F32, "gemm_nt_resid_ln aux", contiguous=False)
+    _, _, ldaux = _rows2d(aux, "gemm_nt_resid_ln aux")
+    _req(gamma, F32, "gemm_nt_resid_ln gamma"); _req(beta, F32, "gemm_nt_resid_ln beta")
+    if bias is not None:
+        _req(bias, F32, "gemm_nt_resid_ln bias")
+    out = torch.empty((M, N), dtype=F32, device=a.device)
+    ln = torch.empty((M, N), dtype=BF16, device=a.device)
+    mean = torch.empty((M,), dtype=F32, device=a.device)
+    rstd = torch.empty((M,), dtype=F32, device=a.device)
+    _lib.check(_L().mmae_gemm_nt_resid_ln(_ptr(a), lda, _ptr(w), ldw, M, N, K, _ptr(bias), _ptr(out), _ptr(aux), ldaux, _ptr(gamma),
+                                          _ptr(beta), float(eps), _ptr(ln), _ptr(mean), _ptr(rstd), _stream()), "gemm_nt_resid_ln")
+    return out, ln, mean, rstd
+
+
 def gemm_tn(x: torch.Tensor, y: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False,
             colsum_out=None, colsum_accumulate: bool = False):
     """out[N,K] (f32) (+)= x[M,N]^T @ y[M,K]. colsum_out: True -> also return the column sums of x (f32 [N]); a tensor ->

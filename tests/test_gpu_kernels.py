@@ -79,6 +79,32 @@ def test_gemm_nt_epilogues(ops, nt_variant):
     assert rel_err(dg.float(), x.grad) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(25344, 768, 768), (25344, 768, 3072), (18496, 1024, 1024), (4000, 768, 768), (50176, 256, 1024),
+                                   (300, 768, 256), (1188, 512, 768)])
+def test_gemm_nt_resid_ln_equals_the_two_kernels(ops, M, N, K):
+    """mmae_gemm_nt_resid_ln = the residual product followed by the LayerNorm of its output.  At the encoder shapes (a tail
+    launch that leaves CUs idle) the leading rows are normalised by workgroups of the tail launch, the rest by the
+    LayerNorm kernel: the same per-row arithmetic, so everything is bitwise what the two separate calls give."""
+    a, w = _randn(M, K, seed=31), _randn(N, K, seed=32, scale=0.05)
+    bias = _randn(N, seed=33, dtype=torch.float32)
+    resid = _randn(M, N, seed=34, dtype=torch.float32) * 3.0
+    gamma, beta = _randn(N, seed=35, dtype=torch.float32) + 1.0, _randn(N, seed=36, dtype=torch.float32)
+    out0 = ops.gemm_nt(ops.EPI_RESID, a, w, bias, aux=resid)
+    ln0, mean0, rstd0 = ops.layernorm_fwd(out0, gamma, beta, 1e-6)
+    for _ in range(2):
+        out, ln, mean, rstd = ops.gemm_nt_resid_ln(a, w, bias, resid, gamma, beta, 1e-6)
+        assert torch.equal(out, out0) and torch.equal(mean, mean0) and torch.equal(rstd, rstd0)
+        assert torch.equal(ln.view(torch.int16), ln0.view(torch.int16))
+    ref = torch.nn.functional.layer_norm(resid + a.float() @ w.float().t() + bias, (N,), gamma, beta, 1e-6)
+    assert rel_err(ln.float(), ref) < 4e-3
+    # without a bias, and with the residual read through a row stride
+    wide = torch.zeros(M, N + 64, dtype=torch.float32, device="cuda")
+    wide[:, 64:] = resid
+    out1, ln1, _, _ = ops.gemm_nt_resid_ln(a, w, None, wide[:, 64:], gamma, beta, 1e-6)
+    out2 = ops.gemm_nt(ops.EPI_RESID, a, w, None, aux=resid)
+    assert torch.equal(out1, out2) and torch.equal(ln1.view(torch.int16), ops.layernorm_fwd(out2, gamma, beta, 1e-6)[0].view(torch.int16))
+
+
 def test_gemm_nt_strided_views(ops, nt_variant):
     # operands / outputs that are column slices of wider buffers (how qkv and kv are consumed)
     M, K = 400, 256
