@@ -207,12 +207,13 @@ int mmae_embed_bwd_reduce(const float* dx, const int* ids_keep_i32, int B, int k
 int mmae_decoder_assemble_fwd(const void* ctx_bf16, const float* mask_token, const float* emb, const int* ids_keep_i32,
                               const int* ids_restore_i32, int B, int k, int G, int total, int q_start, int q_len, int Dd,
                               float* queries, float* context, mmae_stream_t stream);
-/* Gradients of the assembly: d_ctx bf16 [B,k+G,Dd]; d_mask_token f32 [Dd]; d_task_emb_host[t] f32 [Dd]
- * (sum over the positions of task t of the embedding gradient; pos_emb is frozen). Tasks have ntok tokens each. */
+/* Gradients of the assembly: d_ctx bf16 [B,k+G,Dd], rows ld_d_ctx elements apart (0 = Dd; a larger stride lets several
+ * decoders write their gradients side by side as the column blocks of one matrix); d_mask_token f32 [Dd]; d_task_emb_host[t]
+ * f32 [Dd] (sum over the positions of task t of the embedding gradient; pos_emb is frozen). Tasks have ntok tokens each. */
 size_t mmae_decoder_assemble_bwd_workspace_bytes(int B, int T, int Dd);
 int mmae_decoder_assemble_bwd(const float* d_queries, const float* d_context, const int* ids_keep_i32,
                               const int* ids_restore_i32, int B, int k, int G, int T, int ntok, int q_start, int q_len,
-                              int Dd, void* d_ctx_bf16, float* d_mask_token, float* const* d_task_emb_host,
+                              int Dd, void* d_ctx_bf16, long ld_d_ctx, float* d_mask_token, float* const* d_task_emb_host,
                               void* workspace, size_t workspace_bytes, mmae_stream_t stream);
 /* emb[t*ntok + pos][:] = task_emb_t[:] + pos_emb[:, pos]  (multimae/output_adapters.py:195-228) */
 int mmae_build_decoder_emb(const float* const* task_emb_host, const float* pos_emb, int T, int ntok, int Dd, float* emb,

@@ -51,7 +51,7 @@ SIGNATURES = {
     "mmae_embed_bwd_reduce": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, C.POINTER(_p), _p, _p]),
     "mmae_decoder_assemble_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "mmae_decoder_assemble_bwd_workspace_bytes": (_z, [_i, _i, _i]),
-    "mmae_decoder_assemble_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, C.POINTER(_p), _p, _z, _p]),
+    "mmae_decoder_assemble_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _l, _p, C.POINTER(_p), _p, _z, _p]),
     "mmae_build_decoder_emb": (_i, [C.POINTER(_p), _p, _i, _i, _i, _p, _p]),
     "mmae_patchify_bf16": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "mmae_class_emb_bwd_workspace_bytes": (_z, [_i, _i]),

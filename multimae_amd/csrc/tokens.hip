@@ -335,7 +335,7 @@ extern "C" int mmae_decoder_assemble_fwd(const void* ctx_bf16, const float* mask
 struct AsmBwdArgs {
     const float* dq; const float* dc; const int* ids_keep; const int* ids_restore;
     int B, k, G, total, q_start, q_len, Dd, T, ntok;
-    bf16* d_ctx; float* part;  // part[b][T+1][Dd]
+    bf16* d_ctx; long ldc; float* part;  // d_ctx rows are ldc elements apart; part[b][T+1][Dd]
 };
 // grid (B, column splits): a workgroup owns nv = Dd / 4 / gridDim.y column quads of its sample, so that a sample's work (a
 // few hundred KB read more than once) is spread over several CUs instead of one
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(1024) void decoder_assemble_bwd_kernel(AsmBwdArgs a
                 v += ((const f32x4*)(a.dq + ((long)b * a.q_len + pos - a.q_start) * a.Dd))[c];
         }
         bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-        *(bf16x4*)(a.d_ctx + ((long)b * seq + j) * a.Dd + c * 4) = o;
+        *(bf16x4*)(a.d_ctx + ((long)b * seq + j) * a.ldc + c * 4) = o;
     }
     // partial sums over positions: slot t < T collects d_emb of task t, slot T the mask token.
     // threads are laid out as (column group c, position lane pl); each walks positions pl, pl+PL, ...
@@ -424,15 +424,18 @@ extern "C" size_t mmae_decoder_assemble_bwd_workspace_bytes(int B, int T, int Dd
 
 extern "C" int mmae_decoder_assemble_bwd(const float* d_queries, const float* d_context, const int* ids_keep_i32,
                                          const int* ids_restore_i32, int B, int k, int G, int T, int ntok, int q_start, int q_len,
-                                         int Dd, void* d_ctx_bf16, float* d_mask_token, float* const* d_task_emb_host,
+                                         int Dd, void* d_ctx_bf16, long ld_d_ctx, float* d_mask_token, float* const* d_task_emb_host,
                                          void* workspace, size_t workspace_bytes, hipStream_t stream) {
     MMAE_REQUIRE(d_queries && d_context && ids_keep_i32 && ids_restore_i32 && d_ctx_bf16 && d_mask_token && d_task_emb_host && workspace,
                  MMAE_EINVAL, "decoder_assemble_bwd: null pointer");
     MMAE_REQUIRE(T >= 1 && T <= TOK_MAX_TASKS && Dd % 4 == 0 && Dd / 4 <= 256, MMAE_ESHAPE, "decoder_assemble_bwd: bad shape (T=%d Dd=%d)", T, Dd);
     MMAE_REQUIRE(workspace_bytes >= mmae_decoder_assemble_bwd_workspace_bytes(B, T, Dd), MMAE_EWORKSPACE, "decoder_assemble_bwd: workspace too small");
+    if (ld_d_ctx == 0) ld_d_ctx = Dd;
+    MMAE_REQUIRE(ld_d_ctx >= Dd && ld_d_ctx % 4 == 0 && (uintptr_t)d_ctx_bf16 % 8 == 0, MMAE_ESHAPE,
+                 "decoder_assemble_bwd: d_ctx row stride %ld must be >= Dd = %d and a multiple of 4 (rows 8-byte aligned)", ld_d_ctx, Dd);
     if (B == 0) return MMAE_OK;
     AsmBwdArgs a = {d_queries, d_context, ids_keep_i32, ids_restore_i32, B, k, G, T * ntok, q_start, q_len, Dd, T, ntok,
-                    (bf16*)d_ctx_bf16, (float*)workspace};
+                    (bf16*)d_ctx_bf16, ld_d_ctx, (float*)workspace};
     const int splits = (Dd / 4) % 4 == 0 && Dd >= 128 ? 4 : 1;  // column groups of a sample, one workgroup each
     hipLaunchKernelGGL(decoder_assemble_bwd_kernel, dim3(B, splits), dim3(1024), 0, stream, a);
     MMAE_CHECK_LAUNCH("decoder_assemble_bwd");

@@ -667,13 +667,70 @@ class EmbedFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # decoder head: proj_context + query/context assembly + cross-attention + MLP
 # ---------------------------------------------------------------------------------------------
-class DecoderHeadFn(torch.autograd.Function):
-    """multimae/output_adapters.py:341-353 of the reference: enc f32 [B,k+G,D] -> x f32 [B,ntok,Dd]."""
+class ContextFan:
+    """What the decoders of one forward pass share for the gradient of the encoder output.  Every decoder projects the same
+    encoder tokens (proj_context, multimae/output_adapters.py:341 of the reference), so d(enc) = sum_i d_ctx_i W_i: instead
+    of one product and one fp32 [B, seq, D] result per decoder plus the additions between them, the decoders write their d_ctx
+    side by side as the column blocks of one bf16 matrix [B * seq, n * Dd] and ContextFanFn.backward forms the sum as ONE
+    product with the row-concatenated weights (K = n * Dd)."""
+
+    def __init__(self, n: int):
+        self.n, self.dctx, self.wcat, self.written = n, None, None, [False] * n
+
+    def slot(self, i: int, rows: int, dd: int, wt: torch.Tensor):
+        """Decoder i's column block of the d_ctx matrix; its weight block W_i^T [D, Dd] is copied into the K-concatenated
+        weight now, on the decoder's stream: once the decoder has signalled its weight gradient, an optimizer that runs beside
+        backward may rewrite the bf16 weight copies before the fan's product reads them."""
+        dev, cur = wt.device, torch.cuda.current_stream(wt.device)
+        if self.dctx is None:
+            self.dctx = torch.empty((rows, self.n * dd), dtype=torch.bfloat16, device=dev)
+            self.wcat = torch.empty((wt.shape[0], self.n * dd), dtype=torch.bfloat16, device=dev)  # no fill: the decoders write from several streams
+        self.dctx.record_stream(cur)  # allocated on the first decoder's stream, written on each decoder's, read on the fan's
+        self.wcat.record_stream(cur)
+        self.wcat[:, i * dd:(i + 1) * dd].copy_(wt)
+        self.written[i] = True
+        return self.dctx[:, i * dd:(i + 1) * dd]
+
+
+class ContextFanFn(torch.autograd.Function):
+    """enc -> one small proxy tensor per decoder.  A decoder that is given a proxy returns no gradient for the encoder tokens
+    themselves; it leaves d_ctx in its ContextFan slot and a (meaningless) gradient for the proxy, through which autograd
+    orders this node's backward after every decoder's and synchronises their streams with this one."""
 
     @staticmethod
-    def forward(ctx, enc, keep32, restore32, meta, pos_table, mask_token, pc_w, pc_b, qn_w, qn_b, cn_w, cn_b, q_w, q_b,
+    def forward(ctx, enc, fan):
+        ctx.fan, ctx.shape = fan, tuple(enc.shape)
+        ctx.set_materialize_grads(False)
+        return tuple(enc.new_empty(1) for _ in range(fan.n))  # never read: edges of the graph only
+
+    @staticmethod
+    def backward(ctx, *grads):
+        fan, (B, seq, D) = ctx.fan, ctx.shape
+        if fan.dctx is None:  # no decoder ran its backward
+            return None, None
+        dev = fan.dctx.device
+        fan.dctx.record_stream(torch.cuda.current_stream(dev))
+        fan.wcat.record_stream(torch.cuda.current_stream(dev))
+        dd = fan.dctx.shape[1] // fan.n
+        for i in range(fan.n):  # a decoder outside this backward pass contributes nothing
+            if not fan.written[i]:
+                fan.dctx[:, i * dd:(i + 1) * dd].zero_()
+                fan.wcat[:, i * dd:(i + 1) * dd].zero_()
+        d_enc = ops.gemm_nt(ops.EPI_F32, fan.dctx, fan.wcat, None)  # [M, n * Dd] x [D, n * Dd]^T
+        fan.dctx = fan.wcat = None
+        return d_enc.reshape(B, seq, D), None
+
+
+class DecoderHeadFn(torch.autograd.Function):
+    """multimae/output_adapters.py:341-353 of the reference: enc f32 [B,k+G,D] -> x f32 [B,ntok,Dd].
+    tok: None, or this decoder's proxy from ContextFanFn (meta[8] = (ContextFan, index)): the gradient of enc is then left to
+    that node."""
+
+    @staticmethod
+    def forward(ctx, enc, tok, keep32, restore32, meta, pos_table, mask_token, pc_w, pc_b, qn_w, qn_b, cn_w, cn_b, q_w, q_b,
                 kv_w, kv_b, pr_w, pr_b, on_w, on_b, f1w, f1b, f2w, f2b, *task_embs):
         heads, k, G, T, ntok, q_start = meta[:6]
+        ctx.fan = meta[8] if tok is not None and len(meta) > 8 else None
         B, seq, D = enc.shape
         Dd = pc_w.shape[0]
         d = Dd // heads
@@ -721,15 +778,23 @@ class DecoderHeadFn(torch.autograd.Function):
         dwkv, dbkv = _lin_grads(dkv, cn, kv_w, kv_b)
         d_queries, dqnw, dqnb = _ln_bwd(dqn, queries.reshape(B * ntok, Dd), qn_w, qn_b, qmean, qrstd)
         d_context, dcnw, dcnb = _ln_bwd(dcn, context.reshape(B * seq, Dd), cn_w, cn_b, cmean, crstd)
-        d_ctx, d_mask, d_task = ops.decoder_assemble_bwd(d_queries.reshape(B, ntok, Dd), d_context.reshape(B, seq, Dd), keep32,
-                                                         restore32, k, G, T, ntok, q_start, ntok)
-        d_ctx2 = d_ctx.reshape(B * seq, Dd)
-        d_enc = ops.gemm_nt(ops.EPI_F32, d_ctx2, wpct, None).reshape(B, seq, D)
+        d_tok = None
+        if ctx.fan is not None:  # d_ctx into this decoder's column block; the product with proj_context's weight is the fan's
+            fan, slot = ctx.fan
+            d_ctx2, d_mask, d_task = ops.decoder_assemble_bwd(d_queries.reshape(B, ntok, Dd), d_context.reshape(B, seq, Dd), keep32,
+                                                              restore32, k, G, T, ntok, q_start, ntok,
+                                                              d_ctx_out=fan.slot(slot, B * seq, Dd, wpct))
+            d_enc, d_tok = None, g.new_empty(1)  # never read
+        else:
+            d_ctx, d_mask, d_task = ops.decoder_assemble_bwd(d_queries.reshape(B, ntok, Dd), d_context.reshape(B, seq, Dd), keep32,
+                                                             restore32, k, G, T, ntok, q_start, ntok)
+            d_ctx2 = d_ctx.reshape(B * seq, Dd)
+            d_enc = ops.gemm_nt(ops.EPI_F32, d_ctx2, wpct, None).reshape(B, seq, D)
         dwpc, dbpc = _lin_grads(d_ctx2, enc_b, pc_w, pc_b)
         dnw, dnb, df1w, df1b, df2w, df2b = g_mlp
         d_mask = _deliver(mask_token, d_mask)
         d_task = [None if e is None else _deliver(e, d) for d, e in zip(d_task, task_embs)]
-        return (d_enc, None, None, None, None, d_mask, dwpc, dbpc, dqnw, dqnb, dcnw, dcnb, dwq, dbq, dwkv, dbkv, dwpr, dbpr,
+        return (d_enc, d_tok, None, None, None, None, d_mask, dwpc, dbpc, dqnw, dqnb, dcnw, dcnb, dwq, dbq, dwkv, dbkv, dwpr, dbpr,
                 dnw, dnb, df1w, df1b, df2w, df2b, *d_task)
 
 

@@ -23,6 +23,7 @@ __all__ = ["MultiMAE", "pretrain_multimae_base", "pretrain_multimae_large", "cre
 
 import os as _os
 _SHARED_ENC_CAST = _os.environ.get("MMAE_SHARED_ENC_CAST", "1") != "0"  # tuning switch
+_CTX_FAN = _os.environ.get("MMAE_CTX_FAN", "1") != "0"  # tuning switch: one product for the decoders' gradient of the encoder output
 
 
 class MultiMAE(nn.Module):
@@ -227,6 +228,13 @@ class MultiMAE(nn.Module):
             # the streams (DecoderHeadFn would otherwise cast it once per decoder)
             Bq, Nq, Dq = encoder_tokens.shape
             input_info["_enc_bf16"] = ops.cast_bf16(encoder_tokens.detach().contiguous().reshape(Bq * Nq, Dq))
+        # decoders that run the fused head share one product for the gradient of the encoder output (Fn.ContextFan)
+        if encoder_tokens.is_cuda and encoder_tokens.requires_grad and torch.is_grad_enabled() and _CTX_FAN:
+            heads = [a for a in self.output_adapters.values() if hasattr(a, "fused_head") and a.fused_head(input_info)]
+            if len(heads) > 1 and len({a.dim_tokens for a in heads}) == 1:
+                fan = Fn.ContextFan(len(heads))
+                proxies = Fn.ContextFanFn.apply(encoder_tokens, fan)
+                input_info["_ctx_fan"] = {id(a): (fan, i, proxies[i]) for i, a in enumerate(heads)}
         lanes = Fn.decoder_lanes(encoder_tokens.device, len(self.output_adapters)) if encoder_tokens.is_cuda else None
         if lanes is not None:
             # the decoders are independent until the losses: dealt over the main stream and the decoder streams; same

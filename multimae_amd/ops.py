@@ -516,16 +516,25 @@ def decoder_assemble_fwd(ctx, mask_token, emb, keep32, restore32, k, G, q_start,
     return queries, context
 
 
-def decoder_assemble_bwd(d_queries, d_context, keep32, restore32, k, G, T, ntok, q_start, q_len):
+def decoder_assemble_bwd(d_queries, d_context, keep32, restore32, k, G, T, ntok, q_start, q_len, d_ctx_out=None):
+    """d_ctx_out: optional bf16 [B*seq, Dd] view (unit column stride, any row stride) that receives d_ctx, e.g. a column
+    block of a wider matrix; returned reshaped to [B, seq, Dd] only when it is contiguous, else as the 2-D view."""
     _req(d_queries, F32, "decoder_assemble_bwd d_queries"); _req(d_context, F32, "decoder_assemble_bwd d_context")
     B, seq, dd = d_context.shape
     dev = d_context.device
-    d_ctx = torch.empty((B, seq, dd), dtype=BF16, device=dev)
+    if d_ctx_out is None:
+        d_ctx, ldc = torch.empty((B, seq, dd), dtype=BF16, device=dev), dd
+    else:
+        _req(d_ctx_out, BF16, "decoder_assemble_bwd d_ctx_out", contiguous=False)
+        rows, cols, ldc = _rows2d(d_ctx_out, "decoder_assemble_bwd d_ctx_out")
+        if rows != B * seq or cols != dd:
+            raise _lib.MmaeError(f"decoder_assemble_bwd: d_ctx_out is {rows}x{cols}, expected {B * seq}x{dd}")
+        d_ctx = d_ctx_out
     d_mask = torch.empty((1, 1, dd), dtype=F32, device=dev)
     d_task = [torch.empty((1, 1, dd), dtype=F32, device=dev) for _ in range(T)]
     ws = workspace(_L().mmae_decoder_assemble_bwd_workspace_bytes(B, T, dd), dev)
     _lib.check(_L().mmae_decoder_assemble_bwd(_ptr(d_queries), _ptr(d_context), _ptr(keep32), _ptr(restore32), B, k, G, T, ntok,
-                                              q_start, q_len, dd, _ptr(d_ctx), _ptr(d_mask), _ptr_array(d_task), _ptr(ws),
+                                              q_start, q_len, dd, _ptr(d_ctx), ldc, _ptr(d_mask), _ptr_array(d_task), _ptr(ws),
                                               ws.numel(), _stream()), "decoder_assemble_bwd")
     return d_ctx, d_mask, d_task
 

@@ -119,6 +119,12 @@ class SpatialOutputAdapter(nn.Module):
         x = self.decoder(layer_norm(self.query_norm, queries), layer_norm(self.context_norm, context))
         return x + self.mlp(layer_norm(self.out_norm, x))
 
+    def fused_head(self, input_info: Dict) -> bool:
+        """True when forward() runs proj_context .. MLP as the one fused node (the pretraining configuration)."""
+        own_queries = not self.use_task_queries or self.task not in input_info["tasks"]
+        dropping = self.use_xattn and self.training and bool(self.decoder.attn_drop or self.decoder.proj_drop)
+        return not (own_queries or not self.use_xattn or dropping or not self._ln_kernel)
+
     def forward(self, encoder_tokens: Tensor, input_info: Dict, ids_keep: Tensor, ids_restore: Tensor, fp32_output: bool = False):
         assert self.dim_tokens_enc is not None, "Need to call init(dim_tokens_enc) function first"
         H, W = input_info["image_size"]
@@ -147,9 +153,13 @@ class SpatialOutputAdapter(nn.Module):
             x = self.decoder_transformer(x)
             return Fn.OutProjFn.apply(x, self.out_proj.weight, self.out_proj.bias, self.num_channels, self.P_H, nh, nw, fp32_output)
         d, m = self.decoder, self.mlp
-        meta = (self.num_heads, k, G, len(tasks), ntok, q_start, enc_b, (self.query_norm.eps, self.context_norm.eps, self.out_norm.eps))
+        fan = (input_info.get("_ctx_fan") or {}).get(id(self))  # (ContextFan, slot, proxy) set up by MultiMAE.forward
+        if fan is not None and fan[0].n * self.dim_tokens % 8:
+            fan = None
+        meta = (self.num_heads, k, G, len(tasks), ntok, q_start, enc_b, (self.query_norm.eps, self.context_norm.eps, self.out_norm.eps),
+                None if fan is None else fan[:2])
         x = Fn.DecoderHeadFn.apply(
-            encoder_tokens, keep32, restore32, meta, self._pos_table(nh, nw), self.mask_token,
+            encoder_tokens, None if fan is None else fan[2], keep32, restore32, meta, self._pos_table(nh, nw), self.mask_token,
             self.proj_context.weight, self.proj_context.bias, self.query_norm.weight, self.query_norm.bias,
             self.context_norm.weight, self.context_norm.bias, d.q.weight, _b(d.q), d.kv.weight, _b(d.kv), d.proj.weight, d.proj.bias,
             self.out_norm.weight, self.out_norm.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, *embs)
