@@ -104,6 +104,15 @@ def test_vit_b_rgbd_step_vs_oracle():
     # per-tensor: the bar applies to every parameter gradient
     badg = {n: e for n, e in gerr.items() if not e < BF16_TOL}
     assert not badg, badg
+    # What bf16 costs the reference itself: the same oracle under torch.autocast(bfloat16) on the host (the reference's AMP
+    # arithmetic with bf16 as the low-precision type) against its own fp32 run.  The kernels keep scores, probabilities and
+    # the decoder's residual stream in fp32 where autocast rounds them, so they must not be further from fp32 than that is
+    # (scripts/parity_margin.py tabulates both at 2 / 4 / 8 images: worst tensor 1.2e-2 against 1.5e-2 at this size).
+    _, _, _, a_grads = O.step_grads(sd, cfg, x, p, noises, noise_all, k, autocast_dtype=torch.bfloat16)
+    a_worst = max(rel_err(a_grads[n], o_grads[n]) for n in o_grads)
+    a_all = sum(((a_grads[n].double() - o_grads[n].double()) ** 2).sum() for n in o_grads).sqrt().item() / on
+    print(f"autocast(bf16) reference against fp32: worst tensor {a_worst:.2e}, all gradients {a_all:.2e}")
+    assert worst[0][1] <= 1.25 * a_worst and errs["grad_all"] <= 1.25 * a_all, (worst[0], a_worst, errs["grad_all"], a_all)
 
     # bitwise reproducibility of the whole step (no atomics, fixed reduction orders)
     preds2, _, losses2, grads2 = _hip_step(model, cfg, x, (p, noises, noise_all), k)
