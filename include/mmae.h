@@ -201,19 +201,19 @@ int mmae_embed_bwd_reduce(const float* dx, const int* ids_keep_i32, int B, int k
                           float* d_global, float* const* d_bias_host, void* dx_bf16_rows, mmae_stream_t stream);
 
 /* Decoder input assembly (multimae/output_adapters.py:195-314): from ctx = proj_context(encoder tokens)
- * (bf16 [B, k+G, Dd]) build queries f32 [B, ntok, Dd] (own-task slice of the un-shuffled, mask-token-filled,
+ * (bf16 [B, k+G, Dd]; f32 with ctx_is_f32, for a decoder that runs in fp32) build queries f32 [B, ntok, Dd] (own-task slice of the un-shuffled, mask-token-filled,
  * embedded sequence) and context f32 [B, k+G, Dd] (kept tokens + embeddings, global tokens appended raw).
  * emb is f32 [total, Dd] = task_embedding[t] + pos_emb[pos]. */
-int mmae_decoder_assemble_fwd(const void* ctx_bf16, const float* mask_token, const float* emb, const int* ids_keep_i32,
-                              const int* ids_restore_i32, int B, int k, int G, int total, int q_start, int q_len, int Dd,
-                              float* queries, float* context, mmae_stream_t stream);
-/* Gradients of the assembly: d_ctx bf16 [B,k+G,Dd], rows ld_d_ctx elements apart (0 = Dd; a larger stride lets several
+int mmae_decoder_assemble_fwd(const void* ctx_bf16, int ctx_is_f32, const float* mask_token, const float* emb,
+                              const int* ids_keep_i32, const int* ids_restore_i32, int B, int k, int G, int total, int q_start,
+                              int q_len, int Dd, float* queries, float* context, mmae_stream_t stream);
+/* Gradients of the assembly: d_ctx bf16 (f32 with d_ctx_is_f32) [B,k+G,Dd], rows ld_d_ctx elements apart (0 = Dd; a larger stride lets several
  * decoders write their gradients side by side as the column blocks of one matrix); d_mask_token f32 [Dd]; d_task_emb_host[t]
  * f32 [Dd] (sum over the positions of task t of the embedding gradient; pos_emb is frozen). Tasks have ntok tokens each. */
 size_t mmae_decoder_assemble_bwd_workspace_bytes(int B, int T, int Dd);
 int mmae_decoder_assemble_bwd(const float* d_queries, const float* d_context, const int* ids_keep_i32,
                               const int* ids_restore_i32, int B, int k, int G, int T, int ntok, int q_start, int q_len,
-                              int Dd, void* d_ctx_bf16, long ld_d_ctx, float* d_mask_token, float* const* d_task_emb_host,
+                              int Dd, void* d_ctx_bf16, int d_ctx_is_f32, long ld_d_ctx, float* d_mask_token, float* const* d_task_emb_host,
                               void* workspace, size_t workspace_bytes, mmae_stream_t stream);
 /* emb[t*ntok + pos][:] = task_emb_t[:] + pos_emb[:, pos]  (multimae/output_adapters.py:195-228) */
 int mmae_build_decoder_emb(const float* const* task_emb_host, const float* pos_emb, int T, int ntok, int Dd, float* emb,
@@ -292,6 +292,35 @@ int mmae_transpose_multi(const void* src_bf16, void* dst_bf16, const int* table,
                          mmae_stream_t stream);
 /* y(bf16) = x(f32) elementwise */
 int mmae_cast_bf16(const float* x, void* y_bf16, long n, mmae_stream_t stream);
+/* ---- fp32 path of the output adapters listed in fp32_output_adapters (multimae/multimae.py:426-436: the reference runs
+ * those decoders outside autocast, fp32 end to end) ----------------------------------------------------------------
+ * mmae_split_f32: src f32 [rows, cols] (row stride ld_src) -> three bf16 blocks hi = bf16(x), lo = bf16(x - hi) in the order
+ * pattern 0: hi, hi, lo / pattern 1: hi, lo, hi; side by side (dst [rows, 3 * block_cols]) or, with by_rows, stacked (dst
+ * [3 * rows, block_cols]); block_cols (0 = cols) >= cols pads every block with zero columns.  A pattern-0 operand against a pattern-1 operand in mmae_gemm_nt (blocks along K) or mmae_gemm_tn (blocks along M)
+ * gives a_hi w_hi + a_hi w_lo + a_lo w_hi in the fp32 accumulators: nn.Linear with fp32-faithful operands (16 mantissa
+ * bits each) on the bf16 matrix cores. */
+int mmae_split_f32(const float* src, long ld_src, int rows, int cols, void* dst_bf16, int pattern, int by_rows, int block_cols,
+                   mmae_stream_t stream);
+/* nn.GELU (erf form) and dx = dy * gelu'(x), elementwise in fp32; n a multiple of 4 (multimae/multimae_utils.py:164) */
+int mmae_gelu_f32(const float* x, float* y, long n, mmae_stream_t stream);
+int mmae_gelu_bwd_f32(const float* x, const float* dy, float* dx, long n, mmae_stream_t stream);
+/* nn.LayerNorm with fp32 output / fp32 incoming gradient (multimae/output_adapters.py:350-353 outside autocast) */
+int mmae_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int rows,
+                           int dim, float eps, mmae_stream_t stream);
+int mmae_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                           float* dgamma, float* dbeta, int accumulate, int rows, int dim, void* workspace,
+                           size_t workspace_bytes, mmae_stream_t stream);
+/* softmax(q k^T scale) v in fp32 on the vector ALU (multimae/multimae_utils.py:200-204, :240-244 outside autocast); rows
+ * addressed like mmae_attn_fwd; head_dim 32 or 64; the K / V rows (forward, dQ) and the Q / dO rows (dK / dV) of one head must
+ * fit the LDS as f32.  workspace: mmae_attn_f32_bwd_workspace_bytes (rowsum(dO * O)). */
+int mmae_attn_f32_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, float* o, long ldo, float* lse,
+                      int B, int H, int q_len, int kv_len, int head_dim, float scale, mmae_stream_t stream);
+size_t mmae_attn_f32_bwd_workspace_bytes(int B, int H, int q_len);
+int mmae_attn_f32_bwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, const float* o, long ldo,
+                      const float* d_o, long lddo, const float* lse, float* dq, long lddq, float* dk, long lddk, float* dv,
+                      long lddv, int B, int H, int q_len, int kv_len, int head_dim, float scale, void* workspace,
+                      size_t workspace_bytes, mmae_stream_t stream);
+
 /* ---- data-parallel gradient exchange over RCCL ------------------------------------------------------
  * The reference wraps the model in DistributedDataParallel (run_pretraining_multimae.py:224-226: rank-0 parameter
  * broadcast at construction, bucketed gradient all-reduce during backward) over torch.distributed's NCCL backend

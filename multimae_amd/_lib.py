@@ -49,9 +49,9 @@ SIGNATURES = {
     "mmae_build_token_table": (_i, [C.POINTER(_p), C.POINTER(_p), _i, _i, _i, _p, _p]),
     "mmae_append_global": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mmae_embed_bwd_reduce": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, C.POINTER(_p), _p, _p]),
-    "mmae_decoder_assemble_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "mmae_decoder_assemble_fwd": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "mmae_decoder_assemble_bwd_workspace_bytes": (_z, [_i, _i, _i]),
-    "mmae_decoder_assemble_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _l, _p, C.POINTER(_p), _p, _z, _p]),
+    "mmae_decoder_assemble_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _l, _p, C.POINTER(_p), _p, _z, _p]),
     "mmae_build_decoder_emb": (_i, [C.POINTER(_p), _p, _i, _i, _i, _p, _p]),
     "mmae_patchify_bf16": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "mmae_class_emb_bwd_workspace_bytes": (_z, [_i, _i]),
@@ -67,6 +67,14 @@ SIGNATURES = {
     "mmae_cast_transpose": (_i, [_p, _i, _i, _p, _p, _p]),
     "mmae_transpose_multi": (_i, [_p, _p, _p, _i, _i, _p]),
     "mmae_cast_bf16": (_i, [_p, _p, _l, _p]),
+    "mmae_split_f32": (_i, [_p, _l, _i, _i, _p, _i, _i, _i, _p]),
+    "mmae_gelu_f32": (_i, [_p, _p, _l, _p]),
+    "mmae_gelu_bwd_f32": (_i, [_p, _p, _p, _l, _p]),
+    "mmae_layernorm_fwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "mmae_layernorm_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "mmae_attn_f32_fwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "mmae_attn_f32_bwd_workspace_bytes": (_z, [_i, _i, _i]),
+    "mmae_attn_f32_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _p, _l, _p, _p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _i, _f, _p, _z, _p]),
     "mmae_comm_unique_id": (_i, [_p]),
     "mmae_comm_init": (_i, [_p, _i, _i, C.POINTER(_p)]),
     "mmae_comm_allreduce_bucket": (_i, [_p, _p, _z, _i, _p]),

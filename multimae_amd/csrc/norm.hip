@@ -6,8 +6,10 @@
 
 #define LN_MAXV 4  // float4 per lane: dim <= 64 * 4 * LN_MAXV = 1024
 
+// YT = bf16 (the operand type of the product that follows) or float (decoders that run outside the low-precision regime)
+template <typename YT>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, bf16* __restrict__ y,
+                                                            const float* __restrict__ beta, YT* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int rows,
                                                             int dim, float eps) {
     const int lane = threadIdx.x & 63;
@@ -37,15 +39,19 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
     const float rs = rsqrtf(wave_sum(q) / dim + eps);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-    bf16* yr = y + (long)row * dim;
+    YT* yr = y + (long)row * dim;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
             const f32x4 g = ((const f32x4*)gamma)[c], b = ((const f32x4*)beta)[c];
             const f32x4 o = (v[i] - mu) * rs * g + b;
-            bf16x4 ob = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
-            *(bf16x4*)(yr + c * 4) = ob;
+            if constexpr (sizeof(YT) == 4) {
+                *(f32x4*)(yr + c * 4) = o;
+            } else {
+                bf16x4 ob = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+                *(bf16x4*)(yr + c * 4) = ob;
+            }
         }
     }
 }
@@ -62,7 +68,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_rows_kernel(const float* __
 
 // Backward. Each wave walks rows `wave_global, wave_global + total_waves, ...`, keeps its dgamma / dbeta
 // partial sums in registers, and the block writes one partial row pair to `part` at the end.
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
+template <typename DT>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DT* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
                                                             float* __restrict__ dx, bf16* __restrict__ dxb,
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
     }
     for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
         const f32x4* xr = (const f32x4*)(x + (long)row * dim);
-        const bf16* dyr = dy + (long)row * dim;
+        const DT* dyr = dy + (long)row * dim;
         const float mu = mean[row], rs = rstd[row];
         f32x4 xh[LN_MAXV], g[LN_MAXV];
         float s1 = 0.f, s2 = 0.f;
@@ -88,8 +95,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + i * 64;
             if (c < nv) {
-                const bf16x4 d4 = *(const bf16x4*)(dyr + c * 4);
-                const f32x4 d = {(float)d4[0], (float)d4[1], (float)d4[2], (float)d4[3]};
+                f32x4 d;
+                if constexpr (sizeof(DT) == 4) {
+                    d = *(const f32x4*)(dyr + c * 4);
+                } else {
+                    const bf16x4 d4 = *(const bf16x4*)(dyr + c * 4);
+                    d = (f32x4){(float)d4[0], (float)d4[1], (float)d4[2], (float)d4[3]};
+                }
                 xh[i] = (xr[c] - mu) * rs;
                 g[i] = d * gm[i];
                 dg[i] += d * xh[i];
@@ -311,7 +323,7 @@ int mmae_ln_fwd_launch(const float* x, const float* gamma, const float* beta, vo
     else if (env_rows > 0 && dim == 768) { LN_FWD_DIM(3) }
     else if (env_rows > 0 && dim == 1024) { LN_FWD_DIM(4) }
     else
-        hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, (bf16*)y, mean, rstd,
+        hipLaunchKernelGGL(layernorm_fwd_kernel<bf16>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, (bf16*)y, mean, rstd,
                            rows, dim, eps);
 #undef LN_FWD_DIM
 #undef LN_FWD_ROWS
@@ -339,12 +351,37 @@ extern "C" int mmae_layernorm_bwd(const void* dy, const float* x, const float* g
     else if (g_ln_bwd_variant != 1 && dim == 768) LN_BWD_ROWS(3, 1);
     else if (g_ln_bwd_variant != 1 && dim == 1024) LN_BWD_ROWS(4, 1);
     else
-        hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const bf16*)dy, x, gamma, mean, rstd, dres, dx,
+        hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, stream, (const bf16*)dy, x, gamma, mean, rstd, dres, dx,
                            (bf16*)dx_bf16, (float*)workspace, rows, dim);
 #undef LN_BWD_ROWS
     MMAE_CHECK_LAUNCH("layernorm_bwd");
     if (dgamma) return mmae_layernorm_param_reduce(workspace, workspace_bytes, rows, dim, dgamma, dbeta, accumulate, stream);
     return MMAE_OK;
+}
+
+// fp32 in, fp32 out (and an fp32 incoming gradient): the LayerNorms of a decoder that runs in fp32 end to end
+// (fp32_output_adapters, multimae/multimae.py:426-436 of the reference)
+extern "C" int mmae_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                      int rows, int dim, float eps, hipStream_t stream) {
+    MMAE_REQUIRE(x && gamma && beta && y && mean && rstd, MMAE_EINVAL, "layernorm_fwd_f32: null pointer");
+    MMAE_REQUIRE(rows > 0 && dim > 0 && dim % 4 == 0 && dim <= 256 * LN_MAXV, MMAE_ESHAPE,
+                 "layernorm_fwd_f32: dim=%d must be a multiple of 4 and <= %d", dim, 256 * LN_MAXV);
+    hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, rows, dim, eps);
+    MMAE_CHECK_LAUNCH("layernorm_fwd_f32");
+    return MMAE_OK;
+}
+
+extern "C" int mmae_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                      float* dx, float* dgamma, float* dbeta, int accumulate, int rows, int dim, void* workspace,
+                                      size_t workspace_bytes, hipStream_t stream) {
+    MMAE_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, MMAE_EINVAL, "layernorm_bwd_f32: null pointer");
+    MMAE_REQUIRE(rows > 0 && dim > 0 && dim % 4 == 0 && dim <= 256 * LN_MAXV, MMAE_ESHAPE,
+                 "layernorm_bwd_f32: dim=%d must be a multiple of 4 and <= %d", dim, 256 * LN_MAXV);
+    MMAE_REQUIRE(workspace_bytes >= mmae_layernorm_bwd_workspace_bytes(rows, dim), MMAE_EWORKSPACE, "layernorm_bwd_f32: workspace too small");
+    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(ln_bwd_blocks(rows)), dim3(256), 0, stream, dy, x, gamma, mean, rstd,
+                       (const float*)nullptr, dx, (bf16*)nullptr, (float*)workspace, rows, dim);
+    MMAE_CHECK_LAUNCH("layernorm_bwd_f32");
+    return mmae_layernorm_param_reduce(workspace, workspace_bytes, rows, dim, dgamma, dbeta, accumulate, stream);
 }
 
 extern "C" int mmae_layernorm_param_reduce(const void* workspace, size_t workspace_bytes, int rows, int dim, float* dgamma,

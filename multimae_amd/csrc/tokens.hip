@@ -273,10 +273,16 @@ extern "C" int mmae_embed_bwd_reduce(const float* dx, const int* ids_keep_i32, i
 // decoder assembly
 // ---------------------------------------------------------------------------------------------
 struct AsmArgs {
-    const bf16* ctx; const float* mask_token; const float* emb; const int* ids_keep; const int* ids_restore;
+    const void* ctx; int ctx_f32; const float* mask_token; const float* emb; const int* ids_keep; const int* ids_restore;
     int B, k, G, total, q_start, q_len, Dd;
     float* queries; float* context;
 };
+// four consecutive values of row `row` of the projected context (bf16, or f32 for decoders that run in fp32)
+__device__ __forceinline__ f32x4 asm_ctx4(const AsmArgs& a, long row, int c) {
+    if (a.ctx_f32) return *(const f32x4*)((const float*)a.ctx + row * a.Dd + c * 4);
+    const bf16x4 s = *(const bf16x4*)((const bf16*)a.ctx + row * a.Dd + c * 4);
+    return (f32x4){(float)s[0], (float)s[1], (float)s[2], (float)s[3]};
+}
 // one block per output row (queries first, then context rows); Dd/4 <= blockDim
 __global__ __launch_bounds__(64) void decoder_assemble_fwd_kernel(AsmArgs a) {
     const int rows_per_b = a.q_len + a.k + a.G;
@@ -288,8 +294,7 @@ __global__ __launch_bounds__(64) void decoder_assemble_fwd_kernel(AsmArgs a) {
             const int pos = a.q_start + rr;
             const int r = a.ids_restore[(long)b * a.total + pos];
             if (r < a.k) {
-                const bf16x4 s = *(const bf16x4*)(a.ctx + ((long)b * seq + r) * a.Dd + c * 4);
-                v = (f32x4){(float)s[0], (float)s[1], (float)s[2], (float)s[3]};
+                v = asm_ctx4(a, (long)b * seq + r, c);
             } else {
                 v = ((const f32x4*)a.mask_token)[c];
             }
@@ -297,16 +302,14 @@ __global__ __launch_bounds__(64) void decoder_assemble_fwd_kernel(AsmArgs a) {
             ((f32x4*)(a.queries + ((long)b * a.q_len + rr) * a.Dd))[c] = v;
         } else {
             const int j = rr - a.q_len;
-            const bf16x4 s = *(const bf16x4*)(a.ctx + ((long)b * seq + j) * a.Dd + c * 4);
-            v = (f32x4){(float)s[0], (float)s[1], (float)s[2], (float)s[3]};
+            v = asm_ctx4(a, (long)b * seq + j, c);
             if (j < a.k) {
                 // gather(full, ids_keep): full[pos] = (ids_restore[pos] < k ? ctx[ids_restore[pos]] : mask_token) + emb[pos]
                 const int pos = a.ids_keep[(long)b * a.k + j];
                 const int r = a.ids_restore[(long)b * a.total + pos];
                 if (r != j) {
                     if (r < a.k) {
-                        const bf16x4 s2 = *(const bf16x4*)(a.ctx + ((long)b * seq + r) * a.Dd + c * 4);
-                        v = (f32x4){(float)s2[0], (float)s2[1], (float)s2[2], (float)s2[3]};
+                        v = asm_ctx4(a, (long)b * seq + r, c);
                     } else {
                         v = ((const f32x4*)a.mask_token)[c];
                     }
@@ -318,14 +321,14 @@ __global__ __launch_bounds__(64) void decoder_assemble_fwd_kernel(AsmArgs a) {
     }
 }
 
-extern "C" int mmae_decoder_assemble_fwd(const void* ctx_bf16, const float* mask_token, const float* emb, const int* ids_keep_i32,
-                                         const int* ids_restore_i32, int B, int k, int G, int total, int q_start, int q_len,
-                                         int Dd, float* queries, float* context, hipStream_t stream) {
+extern "C" int mmae_decoder_assemble_fwd(const void* ctx_bf16, int ctx_is_f32, const float* mask_token, const float* emb,
+                                         const int* ids_keep_i32, const int* ids_restore_i32, int B, int k, int G, int total,
+                                         int q_start, int q_len, int Dd, float* queries, float* context, hipStream_t stream) {
     MMAE_REQUIRE(ctx_bf16 && mask_token && emb && ids_keep_i32 && ids_restore_i32 && queries && context, MMAE_EINVAL,
                  "decoder_assemble_fwd: null pointer");
     MMAE_REQUIRE(Dd % 4 == 0 && q_start >= 0 && q_start + q_len <= total && k <= total, MMAE_ESHAPE, "decoder_assemble_fwd: bad shape");
     if (B == 0) return MMAE_OK;
-    AsmArgs a = {(const bf16*)ctx_bf16, mask_token, emb, ids_keep_i32, ids_restore_i32, B, k, G, total, q_start, q_len, Dd, queries, context};
+    AsmArgs a = {ctx_bf16, ctx_is_f32, mask_token, emb, ids_keep_i32, ids_restore_i32, B, k, G, total, q_start, q_len, Dd, queries, context};
     hipLaunchKernelGGL(decoder_assemble_fwd_kernel, dim3(B * (q_len + k + G)), dim3(64), 0, stream, a);
     MMAE_CHECK_LAUNCH("decoder_assemble_fwd");
     return MMAE_OK;
@@ -335,7 +338,7 @@ extern "C" int mmae_decoder_assemble_fwd(const void* ctx_bf16, const float* mask
 struct AsmBwdArgs {
     const float* dq; const float* dc; const int* ids_keep; const int* ids_restore;
     int B, k, G, total, q_start, q_len, Dd, T, ntok;
-    bf16* d_ctx; long ldc; float* part;  // d_ctx rows are ldc elements apart; part[b][T+1][Dd]
+    void* d_ctx; int d_ctx_f32; long ldc; float* part;  // d_ctx (bf16 or f32) rows are ldc elements apart; part[b][T+1][Dd]
 };
 // grid (B, column splits): a workgroup owns nv = Dd / 4 / gridDim.y column quads of its sample, so that a sample's work (a
 // few hundred KB read more than once) is spread over several CUs instead of one
@@ -352,8 +355,12 @@ __global__ __launch_bounds__(1024) void decoder_assemble_bwd_kernel(AsmBwdArgs a
             if (pos >= a.q_start && pos < a.q_start + a.q_len)
                 v += ((const f32x4*)(a.dq + ((long)b * a.q_len + pos - a.q_start) * a.Dd))[c];
         }
-        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-        *(bf16x4*)(a.d_ctx + ((long)b * seq + j) * a.ldc + c * 4) = o;
+        if (a.d_ctx_f32) {
+            *(f32x4*)((float*)a.d_ctx + ((long)b * seq + j) * a.ldc + c * 4) = v;
+        } else {
+            bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *(bf16x4*)((bf16*)a.d_ctx + ((long)b * seq + j) * a.ldc + c * 4) = o;
+        }
     }
     // partial sums over positions: slot t < T collects d_emb of task t, slot T the mask token.
     // threads are laid out as (column group c, position lane pl); each walks positions pl, pl+PL, ...
@@ -424,18 +431,18 @@ extern "C" size_t mmae_decoder_assemble_bwd_workspace_bytes(int B, int T, int Dd
 
 extern "C" int mmae_decoder_assemble_bwd(const float* d_queries, const float* d_context, const int* ids_keep_i32,
                                          const int* ids_restore_i32, int B, int k, int G, int T, int ntok, int q_start, int q_len,
-                                         int Dd, void* d_ctx_bf16, long ld_d_ctx, float* d_mask_token, float* const* d_task_emb_host,
+                                         int Dd, void* d_ctx_bf16, int d_ctx_is_f32, long ld_d_ctx, float* d_mask_token, float* const* d_task_emb_host,
                                          void* workspace, size_t workspace_bytes, hipStream_t stream) {
     MMAE_REQUIRE(d_queries && d_context && ids_keep_i32 && ids_restore_i32 && d_ctx_bf16 && d_mask_token && d_task_emb_host && workspace,
                  MMAE_EINVAL, "decoder_assemble_bwd: null pointer");
     MMAE_REQUIRE(T >= 1 && T <= TOK_MAX_TASKS && Dd % 4 == 0 && Dd / 4 <= 256, MMAE_ESHAPE, "decoder_assemble_bwd: bad shape (T=%d Dd=%d)", T, Dd);
     MMAE_REQUIRE(workspace_bytes >= mmae_decoder_assemble_bwd_workspace_bytes(B, T, Dd), MMAE_EWORKSPACE, "decoder_assemble_bwd: workspace too small");
     if (ld_d_ctx == 0) ld_d_ctx = Dd;
-    MMAE_REQUIRE(ld_d_ctx >= Dd && ld_d_ctx % 4 == 0 && (uintptr_t)d_ctx_bf16 % 8 == 0, MMAE_ESHAPE,
+    MMAE_REQUIRE(ld_d_ctx >= Dd && ld_d_ctx % 4 == 0 && (uintptr_t)d_ctx_bf16 % (d_ctx_is_f32 ? 16 : 8) == 0, MMAE_ESHAPE,
                  "decoder_assemble_bwd: d_ctx row stride %ld must be >= Dd = %d and a multiple of 4 (rows 8-byte aligned)", ld_d_ctx, Dd);
     if (B == 0) return MMAE_OK;
     AsmBwdArgs a = {d_queries, d_context, ids_keep_i32, ids_restore_i32, B, k, G, T * ntok, q_start, q_len, Dd, T, ntok,
-                    (bf16*)d_ctx_bf16, ld_d_ctx, (float*)workspace};
+                    d_ctx_bf16, d_ctx_is_f32, ld_d_ctx, (float*)workspace};
     const int splits = (Dd / 4) % 4 == 0 && Dd >= 128 ? 4 : 1;  // column groups of a sample, one workgroup each
     hipLaunchKernelGGL(decoder_assemble_bwd_kernel, dim3(B, splits), dim3(1024), 0, stream, a);
     MMAE_CHECK_LAUNCH("decoder_assemble_bwd");

@@ -922,3 +922,183 @@ class MaskedLossFn(torch.autograd.Function):
         if getattr(ctx, "unit_upstream", False):  # the caller vouched that g is exactly 1 (mark_unit_upstream)
             return d_pred, None, None, None, None, None
         return d_pred * g.to(d_pred.dtype), None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# fp32 path: output adapters listed in fp32_output_adapters run outside the low-precision regime, as the reference runs them
+# outside autocast (multimae/multimae.py:426-436): fp32 activations throughout, LayerNorm / GELU / attention in fp32
+# arithmetic, and every nn.Linear product with fp32-faithful operands (hi + lo bf16 split of both sides, three products in
+# one call of the bf16 MFMA GEMM over K-concatenated operands, fp32 accumulation; csrc/fp32.hip).
+# ---------------------------------------------------------------------------------------------
+_SPLIT_CACHE: Dict[int, tuple] = {}
+
+
+def _kpad(n: int) -> int:
+    """Block width of a split operand whose blocks run along the reduction index: a multiple of 128 when that costs little, so
+    that three blocks make whole k-tiles of the 256x256 GEMM (2128 -> 2176); small widths stay as they are."""
+    return round_up(n, 128) if n >= 512 else n
+
+
+def _split_weights(w: torch.Tensor):
+    """(W split along K for the forward product [N, 3 * kpad(K)], W^T split along K for the input gradient [K, 3 * kpad(N)])
+    of an fp32 weight [N, K], pattern (hi, lo, hi); cached until the parameter changes."""
+    key = id(w)
+    ver = (w._version, _WEIGHT_EPOCH, w.data_ptr())
+    ent = _SPLIT_CACHE.get(key)
+    if ent is not None and ent[0] == ver and ent[1] is w:
+        return ent[2], ent[3]
+    w2 = w.detach().reshape(w.shape[0], -1)
+    wk = ops.split_f32(w2, 1, block_cols=_kpad(w2.shape[1]))
+    wtk = ops.split_f32(w2.t().contiguous(), 1, block_cols=_kpad(w2.shape[0]))
+    _SPLIT_CACHE[key] = (ver, w, wk, wtk)
+    return wk, wtk
+
+
+class LinearF32Fn(torch.autograd.Function):
+    """x W^T + b with fp32-faithful operands, x f32 [..., K] -> f32 [..., N].  Saved for the backward: the split of x (bf16
+    [M, 3 * kpad(K)]), not x itself."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x2 = x.contiguous().reshape(-1, x.shape[-1])
+        wk, wtk = _split_weights(w)
+        xs = ops.split_f32(x2, 0, block_cols=_kpad(x2.shape[1]))  # [hi | hi | lo]
+        y = ops.gemm_nt(ops.EPI_F32, xs, wk, None if b is None else b.detach())
+        ctx.saved = (xs, wtk, (w, b), x.shape)
+        return y.reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        xs, wtk, (w, b), shape = ctx.saved
+        ctx.saved = None
+        K, N = shape[-1], w.shape[0]
+        g2 = g.contiguous().reshape(-1, N)
+        gs = ops.split_f32(g2, 0, block_cols=_kpad(N))  # [hi | hi | lo]
+        dx = ops.gemm_nt(ops.EPI_F32, gs, wtk, None) if ctx.needs_input_grad[0] else None
+        # dW = g^T x and db = colsum(g), the same three terms as three accumulating weight-gradient products over the column
+        # blocks of the two splits: g_hi^T x_hi + g_hi^T x_lo + g_lo^T x_hi; the column sums of g_hi and g_lo ride along
+        bg, bx = gs.shape[1] // 3, xs.shape[1] // 3
+        g_hi, g_lo = gs[:, :N], gs[:, 2 * bg:2 * bg + N]
+        x_hi, x_lo = xs[:, :K], xs[:, 2 * bx:2 * bx + K]
+        dw = torch.empty((N, K), dtype=torch.float32, device=g.device)
+        db = torch.empty((N,), dtype=torch.float32, device=g.device) if b is not None else None
+        ops.gemm_tn(g_hi, x_hi, out=dw, accumulate=False, colsum_out=db, colsum_accumulate=False)
+        ops.gemm_tn(g_hi, x_lo, out=dw, accumulate=True)
+        ops.gemm_tn(g_lo, x_hi, out=dw, accumulate=True, colsum_out=db, colsum_accumulate=True)
+        return (None if dx is None else dx.reshape(shape)), _deliver(w, dw.reshape(w.shape)), _deliver(b, db)
+
+
+class LayerNormF32Fn(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension, f32 in and out."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x2 = x.contiguous().reshape(-1, x.shape[-1])
+        y, mean, rstd = ops.layernorm_fwd_f32(x2, w.detach(), b.detach(), eps)
+        ctx.saved = (x2, mean, rstd, (w, b), x.shape)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, mean, rstd, (w, b), shape = ctx.saved
+        ctx.saved = None
+        dx, dg, db = ops.layernorm_bwd_f32(g.contiguous().reshape(x2.shape), x2, w.detach(), mean, rstd)
+        return dx.reshape(shape), _deliver(w, dg), _deliver(b, db), None
+
+
+class GeluF32Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xc = x.contiguous()
+        ctx.saved = xc
+        return ops.gelu_f32(xc)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, ctx.saved = ctx.saved, None
+        return ops.gelu_bwd_f32(x, g.contiguous())
+
+
+class SelfAttnF32Fn(torch.autograd.Function):
+    """softmax(q k^T scale) v over the packed projection qkv f32 [B*N, 3*H*d] -> f32 [B*N, H*d]."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, H, N, d):
+        D = H * d
+        qkv = qkv.contiguous()
+        o, lse = ops.attn_f32_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, d, d ** -0.5)
+        ctx.saved = (qkv, o, lse, (B, H, N, d))
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, o, lse, (B, H, N, d) = ctx.saved
+        ctx.saved = None
+        D = H * d
+        dqkv = torch.empty_like(qkv)
+        ops.attn_f32_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, g.contiguous(), lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                         B, H, N, N, d, d ** -0.5)
+        return dqkv, None, None, None, None
+
+
+class CrossAttnF32Fn(torch.autograd.Function):
+    """softmax(q k^T scale) v with q f32 [B*Nq, H*d] and the packed context projection kv f32 [B*Nk, 2*H*d]."""
+
+    @staticmethod
+    def forward(ctx, q, kv, B, H, Nq, Nk, d):
+        D = H * d
+        q, kv = q.contiguous(), kv.contiguous()
+        o, lse = ops.attn_f32_fwd(q, kv[:, :D], kv[:, D:], B, H, Nq, Nk, d, d ** -0.5)
+        ctx.saved = (q, kv, o, lse, (B, H, Nq, Nk, d))
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        q, kv, o, lse, (B, H, Nq, Nk, d) = ctx.saved
+        ctx.saved = None
+        D = H * d
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        ops.attn_f32_bwd(q, kv[:, :D], kv[:, D:], o, g.contiguous(), lse, dq, dkv[:, :D], dkv[:, D:], B, H, Nq, Nk, d, d ** -0.5)
+        return dq, dkv, None, None, None, None, None
+
+
+class AssembleF32Fn(torch.autograd.Function):
+    """Queries / context assembly (multimae/output_adapters.py:230-314 of the reference) over an fp32 projected context:
+    ctx f32 [B, k+G, Dd] -> (queries f32 [B, ntok, Dd], context f32 [B, k+G, Dd]); meta = (k, G, T, ntok, q_start)."""
+
+    @staticmethod
+    def forward(ctx_, ctx, keep32, restore32, meta, pos_table, mask_token, *task_embs):
+        k, G, T, ntok, q_start = meta
+        Dd = ctx.shape[-1]
+        emb = ops.build_decoder_emb([None if e is None else e.detach().contiguous() for e in task_embs], pos_table.contiguous(), ntok, Dd)
+        queries, context = ops.decoder_assemble_fwd(ctx.contiguous(), mask_token.detach().contiguous(), emb, keep32, restore32, k, G,
+                                                    q_start, ntok)
+        ctx_.saved = (keep32, restore32, meta, (mask_token, task_embs))
+        return queries, context
+
+    @staticmethod
+    def backward(ctx_, d_queries, d_context):
+        keep32, restore32, (k, G, T, ntok, q_start), (mask_token, task_embs) = ctx_.saved
+        ctx_.saved = None
+        d_ctx, d_mask, d_task = ops.decoder_assemble_bwd(d_queries.contiguous(), d_context.contiguous(), keep32, restore32, k, G, T, ntok,
+                                                         q_start, ntok, f32=True)
+        d_task = [None if e is None else _deliver(e, d) for d, e in zip(d_task, task_embs)]
+        return (d_ctx, None, None, None, None, _deliver(mask_token, d_mask), *d_task)
+
+
+def linear_f32(x, lin):
+    return LinearF32Fn.apply(x, lin.weight, lin.bias)
+
+
+def layer_norm_f32(norm, x):
+    return LayerNormF32Fn.apply(x, norm.weight, norm.bias, norm.eps)
+
+
+def block_f32(blk, x):
+    """multimae_utils.Block in fp32 (the decoder blocks of an fp32 output adapter): x f32 [B, N, D]."""
+    B, N, D = x.shape
+    a, m = blk.attn, blk.mlp
+    qkv = linear_f32(layer_norm_f32(blk.norm1, x), a.qkv)
+    o = SelfAttnF32Fn.apply(qkv.reshape(B * N, 3 * D), B, a.num_heads, N, D // a.num_heads)
+    x = x + linear_f32(o.reshape(B, N, D), a.proj)
+    return x + linear_f32(GeluF32Fn.apply(linear_f32(layer_norm_f32(blk.norm2, x), m.fc1)), m.fc2)

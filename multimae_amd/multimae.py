@@ -217,9 +217,8 @@ class MultiMAE(nn.Module):
         encoder_tokens = Fn.run_blocks(self.encoder, tokens)
         if self.output_adapters is None:
             return encoder_tokens, task_masks
-        # Adapters listed in fp32_output_adapters (reference: multimae/multimae.py:426-436 runs them outside autocast)
-        # return their predictions as the un-rounded fp32 accumulators of out_proj; the matrix products themselves keep
-        # bf16 operands with fp32 accumulation like every other product of the step.
+        # Adapters listed in fp32_output_adapters run in fp32 end to end, as the reference runs them outside autocast
+        # (multimae/multimae.py:426-436): SpatialOutputAdapter._forward_f32.
         def decode(d):
             return self.output_adapters[d](encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep,
                                            ids_restore=ids_restore, fp32_output=d in fp32_output_adapters)
@@ -230,7 +229,8 @@ class MultiMAE(nn.Module):
             input_info["_enc_bf16"] = ops.cast_bf16(encoder_tokens.detach().contiguous().reshape(Bq * Nq, Dq))
         # decoders that run the fused head share one product for the gradient of the encoder output (Fn.ContextFan)
         if encoder_tokens.is_cuda and encoder_tokens.requires_grad and torch.is_grad_enabled() and _CTX_FAN:
-            heads = [a for a in self.output_adapters.values() if hasattr(a, "fused_head") and a.fused_head(input_info)]
+            heads = [a for d, a in self.output_adapters.items()
+                     if hasattr(a, "fused_head") and a.fused_head(input_info) and d not in fp32_output_adapters]
             if len(heads) > 1 and len({a.dim_tokens for a in heads}) == 1:
                 fan = Fn.ContextFan(len(heads))
                 proxies = Fn.ContextFanFn.apply(encoder_tokens, fan)

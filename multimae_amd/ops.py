@@ -505,25 +505,29 @@ def build_decoder_emb(task_embs: Sequence[Optional[torch.Tensor]], pos_emb: torc
 
 
 def decoder_assemble_fwd(ctx, mask_token, emb, keep32, restore32, k, G, q_start, q_len):
-    _req(ctx, BF16, "decoder_assemble ctx")
+    """ctx: the projected context, bf16 [B, seq, Dd] (f32 for a decoder that runs in fp32)."""
+    if ctx.dtype not in (BF16, F32):
+        raise _lib.MmaeError(f"decoder_assemble ctx: dtype {ctx.dtype}")
+    _req(ctx, ctx.dtype, "decoder_assemble ctx")
     B, seq, dd = ctx.shape
     total = restore32.shape[1]
     queries = torch.empty((B, q_len, dd), dtype=F32, device=ctx.device)
     context = torch.empty((B, seq, dd), dtype=F32, device=ctx.device)
-    _lib.check(_L().mmae_decoder_assemble_fwd(_ptr(ctx), _ptr(mask_token), _ptr(emb), _ptr(keep32), _ptr(restore32), B, k, G,
-                                              total, q_start, q_len, dd, _ptr(queries), _ptr(context), _stream()),
+    _lib.check(_L().mmae_decoder_assemble_fwd(_ptr(ctx), int(ctx.dtype == F32), _ptr(mask_token), _ptr(emb), _ptr(keep32), _ptr(restore32),
+                                              B, k, G, total, q_start, q_len, dd, _ptr(queries), _ptr(context), _stream()),
                "decoder_assemble_fwd")
     return queries, context
 
 
-def decoder_assemble_bwd(d_queries, d_context, keep32, restore32, k, G, T, ntok, q_start, q_len, d_ctx_out=None):
+def decoder_assemble_bwd(d_queries, d_context, keep32, restore32, k, G, T, ntok, q_start, q_len, d_ctx_out=None, f32=False):
     """d_ctx_out: optional bf16 [B*seq, Dd] view (unit column stride, any row stride) that receives d_ctx, e.g. a column
-    block of a wider matrix; returned reshaped to [B, seq, Dd] only when it is contiguous, else as the 2-D view."""
+    block of a wider matrix; returned reshaped to [B, seq, Dd] only when it is contiguous, else as the 2-D view.
+    f32: d_ctx in f32 (a decoder that runs in fp32)."""
     _req(d_queries, F32, "decoder_assemble_bwd d_queries"); _req(d_context, F32, "decoder_assemble_bwd d_context")
     B, seq, dd = d_context.shape
     dev = d_context.device
     if d_ctx_out is None:
-        d_ctx, ldc = torch.empty((B, seq, dd), dtype=BF16, device=dev), dd
+        d_ctx, ldc = torch.empty((B, seq, dd), dtype=F32 if f32 else BF16, device=dev), dd
     else:
         _req(d_ctx_out, BF16, "decoder_assemble_bwd d_ctx_out", contiguous=False)
         rows, cols, ldc = _rows2d(d_ctx_out, "decoder_assemble_bwd d_ctx_out")
@@ -534,7 +538,7 @@ def decoder_assemble_bwd(d_queries, d_context, keep32, restore32, k, G, T, ntok,
     d_task = [torch.empty((1, 1, dd), dtype=F32, device=dev) for _ in range(T)]
     ws = workspace(_L().mmae_decoder_assemble_bwd_workspace_bytes(B, T, dd), dev)
     _lib.check(_L().mmae_decoder_assemble_bwd(_ptr(d_queries), _ptr(d_context), _ptr(keep32), _ptr(restore32), B, k, G, T, ntok,
-                                              q_start, q_len, dd, _ptr(d_ctx), ldc, _ptr(d_mask), _ptr_array(d_task), _ptr(ws),
+                                              q_start, q_len, dd, _ptr(d_ctx), int(d_ctx.dtype == F32), ldc, _ptr(d_mask), _ptr_array(d_task), _ptr(ws),
                                               ws.numel(), _stream()), "decoder_assemble_bwd")
     return d_ctx, d_mask, d_task
 
@@ -665,3 +669,77 @@ def transpose_multi(src_flat: torch.Tensor, dst_flat: torch.Tensor, table: torch
     _req(src_flat, BF16, "transpose_multi src"); _req(dst_flat, BF16, "transpose_multi dst"); _req(table, torch.int32, "transpose_multi table")
     _lib.check(_L().mmae_transpose_multi(_ptr(src_flat), _ptr(dst_flat), _ptr(table), table.shape[0], int(total_tiles), _stream()),
                "transpose_multi")
+
+
+# --------------------------------------------------------------------------------------------- fp32 path (fp32_output_adapters)
+def split_f32(x: torch.Tensor, pattern: int, by_rows: bool = False, block_cols: int = 0):
+    """x f32 [rows, cols] (any row stride) -> bf16 blocks hi / lo of x = hi + lo in the order (hi, hi, lo) for pattern 0 and
+    (hi, lo, hi) for pattern 1: [rows, 3 * block_cols], or [3 * rows, block_cols] with by_rows; block_cols (default cols) pads
+    every block with zero columns."""
+    _req(x, F32, "split_f32 x", contiguous=False)
+    rows, cols, ld = _rows2d(x, "split_f32 x")
+    bc = block_cols or cols
+    out = torch.empty((3 * rows, bc) if by_rows else (rows, 3 * bc), dtype=BF16, device=x.device)
+    _lib.check(_L().mmae_split_f32(_ptr(x), ld, rows, cols, _ptr(out), int(pattern), int(by_rows), bc, _stream()), "split_f32")
+    return out
+
+
+def gelu_f32(x: torch.Tensor):
+    _req(x, F32, "gelu_f32 x")
+    y = torch.empty_like(x)
+    _lib.check(_L().mmae_gelu_f32(_ptr(x), _ptr(y), x.numel(), _stream()), "gelu_f32")
+    return y
+
+
+def gelu_bwd_f32(x: torch.Tensor, dy: torch.Tensor):
+    _req(x, F32, "gelu_bwd_f32 x"); _req(dy, F32, "gelu_bwd_f32 dy")
+    dx = torch.empty_like(x)
+    _lib.check(_L().mmae_gelu_bwd_f32(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), _stream()), "gelu_bwd_f32")
+    return dx
+
+
+def layernorm_fwd_f32(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-6):
+    _req(x, F32, "layernorm_f32 x"); _req(gamma, F32, "layernorm_f32 gamma"); _req(beta, F32, "layernorm_f32 beta")
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    y = torch.empty_like(x)
+    mean = torch.empty((rows,), dtype=F32, device=x.device)
+    rstd = torch.empty((rows,), dtype=F32, device=x.device)
+    _lib.check(_L().mmae_layernorm_fwd_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), rows, dim, float(eps),
+                                           _stream()), "layernorm_fwd_f32")
+    return y, mean, rstd
+
+
+def layernorm_bwd_f32(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor):
+    """Returns (dx, dgamma, dbeta), all f32."""
+    _req(dy, F32, "layernorm_bwd_f32 dy"); _req(x, F32, "layernorm_bwd_f32 x")
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    dx = torch.empty_like(x)
+    dgamma = torch.empty((dim,), dtype=F32, device=x.device)
+    dbeta = torch.empty((dim,), dtype=F32, device=x.device)
+    ws = workspace(_L().mmae_layernorm_bwd_workspace_bytes(rows, dim), x.device)
+    _lib.check(_L().mmae_layernorm_bwd_f32(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dgamma), _ptr(dbeta), 0,
+                                           rows, dim, _ptr(ws), ws.numel(), _stream()), "layernorm_bwd_f32")
+    return dx, dgamma, dbeta
+
+
+def attn_f32_fwd(q, k, v, B, H, q_len, kv_len, head_dim, scale):
+    """fp32 attention; q / k / v: f32 row-strided 2-D views as in attn_fwd.  Returns (o f32 [B*q_len, H*d], lse [B,H,q_len])."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _req(t, F32, f"attn_f32_fwd {n}", contiguous=False)
+    o = torch.empty((B * q_len, H * head_dim), dtype=F32, device=q.device)
+    lse = torch.empty((B, H, q_len), dtype=F32, device=q.device)
+    _lib.check(_L().mmae_attn_f32_fwd(_ptr(q), _head_view(q, "q"), _ptr(k), _head_view(k, "k"), _ptr(v), _head_view(v, "v"), _ptr(o),
+                                      o.stride(0), _ptr(lse), B, H, q_len, kv_len, head_dim, float(scale), _stream()), "attn_f32_fwd")
+    return o, lse
+
+
+def attn_f32_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, q_len, kv_len, head_dim, scale):
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (d_o, "dO"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        _req(t, F32, f"attn_f32_bwd {n}", contiguous=False)
+    ws = workspace(_L().mmae_attn_f32_bwd_workspace_bytes(B, H, q_len), q.device)
+    _lib.check(_L().mmae_attn_f32_bwd(_ptr(q), _head_view(q, "q"), _ptr(k), _head_view(k, "k"), _ptr(v), _head_view(v, "v"), _ptr(o),
+                                      _head_view(o, "o"), _ptr(d_o), _head_view(d_o, "dO"), _ptr(lse), _ptr(dq), _head_view(dq, "dq"),
+                                      _ptr(dk), _head_view(dk, "dk"), _ptr(dv), _head_view(dv, "dv"), B, H, q_len, kv_len, head_dim,
+                                      float(scale), _ptr(ws), ws.numel(), _stream()), "attn_f32_bwd")

@@ -125,6 +125,37 @@ class SpatialOutputAdapter(nn.Module):
         dropping = self.use_xattn and self.training and bool(self.decoder.attn_drop or self.decoder.proj_drop)
         return not (own_queries or not self.use_xattn or dropping or not self._ln_kernel)
 
+    def _fp32_ready(self) -> bool:
+        """The fp32 path serves the standard decoder (plain nn.Linear / nn.LayerNorm modules, GELU, head_dim 32 or 64)."""
+        blocks = list(self.decoder_transformer) if isinstance(self.decoder_transformer, nn.Sequential) else []
+        hd = self.dim_tokens // self.num_heads
+        return (hd in (32, 64) and self.mlp.act is None and all(b.fused_node() for b in blocks)
+                and all(b.attn.qkv.bias is not None for b in blocks) and self.decoder.q.bias is not None)
+
+    def _forward_f32(self, encoder_tokens, keep32, restore32, dims, embs, nh, nw):
+        """The decoder in fp32 end to end, as the reference runs the adapters listed in fp32_output_adapters outside autocast
+        (multimae/multimae.py:426-436 there): fp32 activations, LayerNorm / GELU / softmax in fp32, every product with
+        fp32-faithful operands (functional.LinearF32Fn).  Returns the prediction in fp32."""
+        k, G, T, ntok, q_start = dims
+        B, seq, _ = encoder_tokens.shape
+        Dd, H = self.dim_tokens, self.num_heads
+        ctx = Fn.linear_f32(encoder_tokens.float(), self.proj_context)
+        queries, context = Fn.AssembleF32Fn.apply(ctx, keep32, restore32, (k, G, T, ntok, q_start), self._pos_table(nh, nw),
+                                                  self.mask_token, *embs)
+        d = self.decoder
+        q = Fn.linear_f32(Fn.layer_norm_f32(self.query_norm, queries), d.q)
+        kv = Fn.linear_f32(Fn.layer_norm_f32(self.context_norm, context), d.kv)
+        o = Fn.CrossAttnF32Fn.apply(q.reshape(B * ntok, Dd), kv.reshape(B * seq, 2 * Dd), B, H, ntok, seq, Dd // H)
+        x = Fn.linear_f32(o.reshape(B, ntok, Dd), d.proj)  # replaces the queries: no residual here (output_adapters.py:350-352)
+        x = x + Fn.linear_f32(Fn.GeluF32Fn.apply(Fn.linear_f32(Fn.layer_norm_f32(self.out_norm, x), self.mlp.fc1)), self.mlp.fc2)
+        if isinstance(self.decoder_transformer, nn.Sequential):
+            for blk in self.decoder_transformer:
+                x = Fn.block_f32(blk, x)
+        y = Fn.linear_f32(x, self.out_proj)  # [B, nh * nw, C * P * P]
+        C, P = self.num_channels, self.P_H
+        # "b (nh nw) (c ph pw) -> b c (nh ph) (nw pw)" (output_adapters.py:364-372)
+        return y.reshape(B, nh, nw, C, P, P).permute(0, 3, 1, 4, 2, 5).reshape(B, C, nh * P, nw * P)
+
     def forward(self, encoder_tokens: Tensor, input_info: Dict, ids_keep: Tensor, ids_restore: Tensor, fp32_output: bool = False):
         assert self.dim_tokens_enc is not None, "Need to call init(dim_tokens_enc) function first"
         H, W = input_info["image_size"]
@@ -152,6 +183,8 @@ class SpatialOutputAdapter(nn.Module):
             x = self._unfused_head(encoder_tokens, keep32, restore32, (k, G, len(tasks), ntok, q_start, own_queries), enc_b, tasks, embs, nh, nw)
             x = self.decoder_transformer(x)
             return Fn.OutProjFn.apply(x, self.out_proj.weight, self.out_proj.bias, self.num_channels, self.P_H, nh, nw, fp32_output)
+        if fp32_output and self._fp32_ready():
+            return self._forward_f32(encoder_tokens, keep32, restore32, (k, G, len(tasks), ntok, q_start), embs, nh, nw)
         d, m = self.decoder, self.mlp
         fan = (input_info.get("_ctx_fan") or {}).get(id(self))  # (ContextFan, slot, proxy) set up by MultiMAE.forward
         if fan is not None and fan[0].n * self.dim_tokens % 8:

@@ -8,6 +8,7 @@ from tests.conftest import rel_err
 
 pytestmark = pytest.mark.gpu
 BF16_TOL = 2e-2
+FP32_TOL = 1e-4
 
 
 def _build(cfg):
@@ -284,6 +285,56 @@ def test_three_domain_semseg_model_vs_reference_golden():
     bad = {k: v for k, v in report.items() if not v < BF16_TOL}
     assert not bad, bad
     assert all(p.grad is not None for p in named.values() if p.requires_grad)
+
+
+def test_fp32_output_adapter_matches_the_fp32_oracle_on_the_same_encoder_tokens():
+    """fp32_output_adapters (multimae/multimae.py:426-436 of the reference: the listed decoders run outside autocast): the
+    semseg decoder of the ViT-B configuration (133 classes at stride 4, decoder width 256, depth 2) fed the SAME fp32 encoder
+    tokens as the oracle's decoder, so that what is compared is the decoder's own arithmetic: logits, masked cross entropy,
+    every decoder parameter gradient and the gradient of the encoder tokens to 1e-4 (L2 norm per tensor)."""
+    import multimae_amd as M
+    from oracle import multimae_oracle as O
+    from tests.golden import common as G
+    cfg = O.vit_b_rgbd_semseg_cfg(extra_norm_pix=False)
+    sd = G.perturbed_state(cfg, seed=31)
+    B, k, D = 3, 98, cfg["dim"]
+    g = torch.Generator().manual_seed(32)
+    p, noises, noise_all = O.draw_mask_randomness(B, [196] * 3, 1.0, g)
+    o_masks, ids_keep, ids_restore = O.generate_masks(p, noises, noise_all, k)
+    enc = torch.randn(B, k + cfg["num_global"], D, generator=g) * 1.5
+    target = torch.randint(0, 133, (B, 56, 56), generator=g)
+    prefix = "output_adapters.semseg"
+    # oracle: fp32 decoder + masked CE, gradients of its parameters and of the encoder tokens
+    osd = {n: (t.clone().requires_grad_(True) if n.startswith(prefix) and t.is_floating_point() and not n.endswith("pos_emb") else t)
+           for n, t in sd.items()}
+    enc_o = enc.clone().requires_grad_(True)
+    names = list(cfg["in_domains"].keys())
+    o_pred = O.output_adapter(enc_o, osd, prefix, cfg, 133, "semseg", ids_keep, ids_restore, (224, 224), patch=O.domain_patch(cfg, "semseg"))
+    o_loss = O.masked_ce(o_pred, target, o_masks[names.index("semseg")], patch_size=16, stride=4)
+    o_loss.backward()
+    # this package: the adapter alone, fp32_output=True
+    model = _build_semseg(cfg)
+    model.load_state_dict(sd, strict=True)
+    model.cuda()
+    adapter = model.output_adapters["semseg"]
+    info = model.generate_input_info({d: torch.empty(B, 196, 0) for d in names}, image_size=(224, 224))
+    enc_g = enc.cuda().requires_grad_(True)
+    pred = adapter(encoder_tokens=enc_g, input_info=info, ids_keep=ids_keep.cuda(), ids_restore=ids_restore.cuda(), fp32_output=True)
+    assert pred.dtype == torch.float32 and pred.shape == (B, 133, 56, 56)
+    loss = M.MaskedCrossEntropyLoss(16, 4)(pred, target.cuda(), mask=o_masks[names.index("semseg")].cuda())
+    loss.backward()
+    errs = {"pred": rel_err(pred.detach().cpu(), o_pred.detach()), "loss": abs(loss.item() - o_loss.item()) / abs(o_loss.item()),
+            "d_enc": rel_err(enc_g.grad.cpu(), enc_o.grad)}
+    for n, q in adapter.named_parameters():
+        if q.requires_grad:
+            errs[n] = rel_err(q.grad.cpu(), osd[f"{prefix}.{n}"].grad)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print("fp32 decoder against the fp32 oracle:", [(n, f"{e:.1e}") for n, e in worst])
+    assert all(e < FP32_TOL for e in errs.values()), worst
+    # the same decoder in the step's usual arithmetic (bf16 operands) for comparison: two orders of magnitude further away
+    adapter.zero_grad(set_to_none=True)
+    pred_b = adapter(encoder_tokens=enc.cuda(), input_info=info, ids_keep=ids_keep.cuda(), ids_restore=ids_restore.cuda())
+    assert pred_b.dtype == torch.bfloat16 and rel_err(pred_b.float().cpu(), o_pred.detach()) > 10 * errs["pred"]
 
 
 def test_vit_b_rgb_depth_semseg_step_vs_oracle():
