@@ -142,6 +142,10 @@ int mmae_layernorm_param_reduce(const void* workspace, size_t workspace_bytes, i
  * tile); accumulation in registers, no atomics; workspace holds rowsum(dO*O) [B,H,q_len] f32 for the two-kernel form. */
 int mmae_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
                   float* lse, int B, int H, int q_len, int kv_len, int head_dim, float scale, mmae_stream_t stream);
+/* Kernel choice for mmae_attn_fwd: 0 = by size (default), 1 = K / V of a head resident in LDS, 2 = keys streamed through LDS
+ * in 64-key tiles with a running softmax (default where the resident images exceed half of the LDS; no limit on kv_len).
+ * Per calling thread; for tests and tuning. */
+void mmae_attn_fwd_set_variant(int variant);
 /* Longest sequence one call takes at this head_dim (a multiple of 32; 0 for an unsupported head_dim): backward = 0: kv_len
  * of mmae_attn_fwd (q_len is not limited there); backward = 1: q_len and kv_len of mmae_attn_bwd.  Longer sequences are
  * served by the caller in chunks of keys (forward: partial outputs merged through their log-sum-exps) and of queries x

@@ -104,25 +104,81 @@ __device__ __forceinline__ bf16x8 row_frag(const bf16* X, int row, int ks, int h
     return *(const bf16x8*)(X + row * (D + 8) + ks * 16 + h2 * 8);
 }
 
+// The same two images without the 8 padding columns: row stride D, the 16-byte chunk c of row n stored at chunk
+// c ^ swz<D>(n), which spreads the rows a fragment read touches over the banks as the padding does.  Used where the padding
+// alone decides whether two workgroups share a CU (289 keys at head_dim 64: 2 x 320 x 72 x 2 = 92 KiB padded, 75 KiB here).
+template <int D>
+__device__ __forceinline__ int swz(int row) { return D == 64 ? (row & 7) : ((row >> 1) & 3); }
+
+template <int D>
+__device__ __forceinline__ bf16x8 row_frag_sw(const bf16* X, int row, int ks, int h2) {
+    return *(const bf16x8*)(X + row * D + (((ks * 2 + h2) ^ swz<D>(row)) << 3));
+}
+
+template <int D>
+__device__ __forceinline__ bf16x8 tr_frag_sw(const bf16* X, int n0, int dd0, int lane) {
+    const int i = lane & 15, h2 = lane >> 5, rhalf = (lane >> 4) & 1;
+    const int row = n0 + 4 * h2 + (i >> 2), col = dd0 + 16 * rhalf + 4 * (i & 3);
+    // rows n and n + 8 share the swizzle (8 is a multiple of its period)
+    const bf16* p = X + row * D + (((col >> 3) ^ swz<D>(row)) << 3) + (col & 7);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p + 8 * D));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// K rows [0, kv_len) and V rows [0, v_rows) (zero from kv_len on) into swizzled images; U chunks of each in flight
+template <int D, int U>
+__device__ __forceinline__ void stage_rows2_sw(const bf16* a, long lda, const bf16* b, long ldb, int n_valid, int v_rows, bf16* img_a, bf16* img_b,
+                                               int tid, int nthreads) {
+    constexpr int CH = D / 8;
+    for (int base = tid; base < v_rows * CH; base += U * nthreads) {
+        bf16x8 va[U], vb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * nthreads, n = idx / CH, c = idx - n * CH;
+            const long nc = n < n_valid ? n : n_valid - 1;
+            va[u] = *(const bf16x8*)(a + nc * lda + c * 8);
+            vb[u] = *(const bf16x8*)(b + nc * ldb + c * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * nthreads, n = idx / CH, c = idx - n * CH;
+            if (idx < v_rows * CH) {
+                const bool ok = n < n_valid;
+                const int off = n * D + ((c ^ swz<D>(n)) << 3);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vb[u][e] = ok ? vb[u][e] : (bf16)0.f;
+                if (ok) *(bf16x8*)(img_a + off) = va[u];
+                *(bf16x8*)(img_b + off) = vb[u];
+            }
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // forward: two passes over the key tiles per 32-query block (row maximum first, then exp / P V), so only one score
 // tile is live at a time; the second Q K^T costs D/16 MFMAs per tile.
 // --------------------------------------------------------------------------------------------
-template <int D>
+template <int D, bool SWZ = false>
 __device__ __forceinline__ f32x16 score_tile(const bf16* Ks, int kt, int r, int h2, const bf16x8* qf) {
     f32x16 a = zero16();
 #pragma unroll
     for (int ks = 0; ks < D / 16; ++ks)
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Ks, kt * 32 + r, ks, h2), qf[ks], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SWZ ? row_frag_sw<D>(Ks, kt * 32 + r, ks, h2) : row_frag<D>(Ks, kt * 32 + r, ks, h2), qf[ks], a,
+                                                    0, 0, 0);
     return a;
 }
 
-template <int D, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p, int nkp) {
+// SWZ: unpadded swizzled images, K rows [0, kv_len) followed by V rows [0, v_rows) where v_rows covers the rows the last
+// tile's P V steps read (16 or 32 past the last full tile; zero from kv_len on).  The last key tile's score MFMAs then read
+// K rows past kv_len out of the V image (the launcher sizes the allocation so that they stay inside it): those score rows
+// are replaced by -inf / 0 through selects before any arithmetic, as the padded layout's zero rows are.
+template <int D, int NW, bool SWZ, int WPE>
+__global__ __launch_bounds__(NW * 64, WPE) void attn_fwd_kernel(AttnArgs p, int nkp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int LDR = D + 8, KS = D / 16, DT = D / 32;
-    bf16* Ks = (bf16*)smem;     // [nkp][LDR]
-    bf16* Vs = Ks + nkp * LDR;  // [nkp][LDR]
+    constexpr int LDR = SWZ ? D : D + 8, KS = D / 16, DT = D / 32;
+    bf16* Ks = (bf16*)smem;                                  // [nkp][LDR]   (SWZ: [kv_len][D])
+    bf16* Vs = Ks + (SWZ ? p.kv_len : nkp) * LDR;            // [nkp][LDR]   (SWZ: [v_rows][D])
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h2 = lane >> 5;
     const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
@@ -130,13 +186,18 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p, int nkp) 
     // every kernel argument in registers before the first branch (otherwise the pointers are fetched behind it: a second
     // scalar round trip before the first load of a workgroup that lives about 15 us)
     asm volatile("" ::"s"(p.q), "s"(p.k), "s"(p.v), "s"(p.o), "s"(p.lse), "s"(p.ldq), "s"(p.ldk), "s"(p.ldv), "s"(p.ldo));
-    stage_pair<D>(p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.kv_len, nkp, Ks, Vs,
-                  tid, NW * 64);
+    const int nkt = nkp / 32;
+    const int tail = p.kv_len - (nkt - 1) * 32;  // valid keys in the last tile (1..32)
+    if (SWZ)
+        stage_rows2_sw<D, 4>(p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.kv_len,
+                             nkp - (tail <= 16 ? 16 : 0), Ks, Vs, tid, NW * 64);
+    else
+        stage_pair<D>(p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.kv_len, nkp, Ks, Vs,
+                      tid, NW * 64);
     __syncthreads();
 
     const float c = p.scale * LOG2E;
-    const int nqt = (p.q_len + 31) / 32, nkt = nkp / 32;
-    const int tail = p.kv_len - (nkt - 1) * 32;  // valid keys in the last tile (1..32)
+    const int nqt = (p.q_len + 31) / 32;
     for (int qb = wave; qb < nqt; qb += NW) {
         const int qrow = qb * 32 + r;
         const int qc = qrow < p.q_len ? qrow : p.q_len - 1;
@@ -147,7 +208,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p, int nkp) 
 
         float m = -INFINITY;
         for (int kt = 0; kt < nkt; ++kt) {
-            const f32x16 a = score_tile<D>(Ks, kt, r, h2, qf);
+            const f32x16 a = score_tile<D, SWZ>(Ks, kt, r, h2, qf);
             // only the last key tile has padded keys to mask (workgroup-uniform test; the vector ALU bounds these kernels)
             if (kt == nkt - 1 && tail < 32) {
                 // accumulator registers 4g..4g+3 hold key rows 8g..8g+7 of the tile: groups past the last key are skipped
@@ -170,7 +231,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p, int nkp) 
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) oacc[dt] = zero16();
         for (int kt = 0; kt < nkt; ++kt) {
-            f32x16 a = score_tile<D>(Ks, kt, r, h2, qf);
+            f32x16 a = score_tile<D, SWZ>(Ks, kt, r, h2, qf);
             const bool short_tail = kt == nkt - 1 && tail <= 16;  // the second k-step of P V would multiply zeros
             if (kt == nkt - 1 && tail < 32) {
 #pragma unroll
@@ -202,7 +263,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p, int nkp) 
                 const bf16x8 pf = pack8(a, s2);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vs, LDR, kt * 32 + 16 * s2, dt * 32, lane), pf, oacc[dt], 0, 0, 0);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SWZ ? tr_frag_sw<D>(Vs, kt * 32 + 16 * s2, dt * 32, lane) : tr_frag(Vs, LDR, kt * 32 + 16 * s2, dt * 32, lane), pf,
+                                                                       oacc[dt], 0, 0, 0);
             }
         }
         l += __shfl_xor(l, 32, 64);
@@ -218,6 +280,169 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p, int nkp) 
                                  (bf16)(oacc[dt][4 * i4 + 2] * inv), (bf16)(oacc[dt][4 * i4 + 3] * inv)};
                     *(bf16x4*)(op + 8 * i4) = ov;
                 }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// forward for key sequences whose whole K / V image would take more than half of the LDS (one workgroup per CU, a handful
+// of waves to hide every latency behind): the keys stream through a ring of two 64-key tiles instead.  A workgroup owns
+// NWQ consecutive 32-query blocks of one (batch, head), one per wave; all waves walk the key tiles together: the next
+// tile's K / V chunks are requested into registers before the current tile is computed and stored to the other ring slot
+// after it, one barrier per tile.  One pass with a running maximum: per 64-key tile the two score tiles, their maximum,
+// one correction of the output accumulators (exp2 of the maximum's change), then exp / P V as in the resident kernel.
+// LDS: 2 slots x (K tile + V tile) x 64 rows x (D + 8) bf16 = 36 KiB at head_dim 64, so four workgroups share a CU.
+// --------------------------------------------------------------------------------------------
+template <int D, int NWQ>
+__global__ __launch_bounds__(NWQ * 64, 4) void attn_fwd_stream_kernel(AttnArgs p, int qblocks_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LDR = D + 8, KS = D / 16, DT = D / 32, CH = D / 8, NT = NWQ * 64;
+    constexpr int TILE = 64 * LDR;               // elements of one K (or V) tile image
+    constexpr int PER = (64 * CH + NT - 1) / NT;  // 16-byte chunks per thread, operand and tile
+    bf16* ring = (bf16*)smem;                    // [2 slots][K tile | V tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h2 = lane >> 5;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int qb = blockIdx.y * qblocks_per_wg + wave;   // this wave's 32-query block
+    const int nqt = (p.q_len + 31) / 32, nt = (p.kv_len + 63) / 64;
+    const bool active = wave < qblocks_per_wg && qb < nqt;  // idle waves still stage and meet the barriers
+    asm volatile("" ::"s"(p.q), "s"(p.k), "s"(p.v), "s"(p.o), "s"(p.lse), "s"(p.ldq), "s"(p.ldk), "s"(p.ldv), "s"(p.ldo));
+    const bf16* kbase = p.k + (long)b * p.kv_len * p.ldk + h * D;
+    const bf16* vbase = p.v + (long)b * p.kv_len * p.ldv + h * D;
+
+    bf16x8 kreg[PER], vreg[PER];
+    auto fetch = [&](int t) {  // tile t -> registers (rows past the end: the last row, zeroed when stored)
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = tid + u * NT, n = idx / CH, c = idx - n * CH;
+            const int key = t * 64 + n;
+            const long kc = key < p.kv_len ? key : p.kv_len - 1;
+            if (idx < 64 * CH) {
+                kreg[u] = *(const bf16x8*)(kbase + kc * p.ldk + c * 8);
+                vreg[u] = *(const bf16x8*)(vbase + kc * p.ldv + c * 8);
+            }
+        }
+    };
+    auto store = [&](int t) {
+        bf16* Kt = ring + (t & 1) * 2 * TILE;
+        bf16* Vt = Kt + TILE;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = tid + u * NT, n = idx / CH, c = idx - n * CH;
+            if (idx < 64 * CH) {
+                const bool ok = t * 64 + n < p.kv_len;
+                bf16x8 kv = kreg[u], vv = vreg[u];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { kv[e] = ok ? kv[e] : (bf16)0.f; vv[e] = ok ? vv[e] : (bf16)0.f; }
+                *(bf16x8*)(Kt + n * LDR + c * 8) = kv;
+                *(bf16x8*)(Vt + n * LDR + c * 8) = vv;
+            }
+        }
+    };
+    fetch(0);
+    // the wave's query fragments, requested beside the first tile
+    const int qrow = qb * 32 + r;
+    const int qc = qrow < p.q_len ? qrow : p.q_len - 1;
+    bf16x8 qf[KS];
+    {
+        const bf16* qp = p.q + ((long)b * p.q_len + (active ? qc : 0)) * p.ldq + h * D + h2 * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+    }
+    store(0);
+    __syncthreads();
+
+    const float c = p.scale * LOG2E;
+    float m = -INFINITY, l = 0.f;
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) oacc[dt] = zero16();
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) fetch(t + 1);
+        const bf16* Kt = ring + (t & 1) * 2 * TILE;
+        const bf16* Vt = Kt + TILE;
+        if (active) {
+            const int valid = p.kv_len - t * 64;          // keys of this tile (1..64 for the last, >= 64 before)
+            const bool two = valid > 32;                 // the second 32-key half holds keys at all
+            f32x16 a0 = score_tile<D>(Kt, 0, r, h2, qf), a1 = zero16();
+            if (two) a1 = score_tile<D>(Kt, 1, r, h2, qf);
+            // maximum over the tile's valid keys
+            float mt = -INFINITY;
+            const int v0 = valid < 32 ? valid : 32, v1 = valid - 32 < 32 ? valid - 32 : 32;
+            if (v0 < 32) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mt = fmaxf(mt, acc_row(i, h2) < v0 ? a0[i] : -INFINITY);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mt = fmaxf(mt, a0[i]);
+            }
+            if (two) {
+                if (v1 < 32) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) mt = fmaxf(mt, acc_row(i, h2) < v1 ? a1[i] : -INFINITY);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) mt = fmaxf(mt, a1[i]);
+                }
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float mn = fmaxf(m, mt);
+            const float corr = __builtin_amdgcn_exp2f((m - mn) * c);  // 0 on the first tile (m = -inf)
+            m = mn;
+            const float mc = -mn * c;
+            l *= corr;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[dt][i] *= corr;
+            // exp / P V, half by half
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (half == 1 && !two) continue;
+                f32x16& a = half == 0 ? a0 : a1;
+                const int vh = half == 0 ? v0 : v1;
+                if (vh < 32) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float e = acc_row(i, h2) < vh ? __builtin_amdgcn_exp2f(fmaf(a[i], c, mc)) : 0.f;
+                        a[i] = e;
+                        l += e;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float e = __builtin_amdgcn_exp2f(fmaf(a[i], c, mc));
+                        a[i] = e;
+                        l += e;
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    if (s2 == 1 && vh <= 16) continue;  // the second k-step would multiply zeros
+                    const bf16x8 pf = pack8(a, s2);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+                        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, LDR, half * 32 + 16 * s2, dt * 32, lane), pf, oacc[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (t + 1 < nt) store(t + 1);  // the other slot: every wave left it at the previous barrier
+        __syncthreads();
+    }
+    if (!active) return;
+    l += __shfl_xor(l, 32, 64);
+    if (h2 == 0 && qrow < p.q_len) p.lse[((long)b * p.H + h) * p.q_len + qrow] = m * p.scale + logf(l);
+    const float inv = 1.0f / l;
+    if (qrow < p.q_len) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            bf16* op = p.o + ((long)b * p.q_len + qrow) * p.ldo + h * D + dt * 32 + 4 * h2;
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                bf16x4 ov = {(bf16)(oacc[dt][4 * i4] * inv), (bf16)(oacc[dt][4 * i4 + 1] * inv),
+                             (bf16)(oacc[dt][4 * i4 + 2] * inv), (bf16)(oacc[dt][4 * i4 + 3] * inv)};
+                *(bf16x4*)(op + 8 * i4) = ov;
             }
         }
     }
@@ -735,7 +960,45 @@ template <int D, int NW>
 static int launch_fwd(const AttnArgs& a, hipStream_t s) {
     static bool reserved = false;
     const int nkp = pad32(a.kv_len);
-    return launch_with_lds(attn_fwd_kernel<D, NW>, "attn_fwd", sizeof(bf16) * 2 * (size_t)nkp * (D + 8), a.B * a.H, NW * 64, s, a, nkp, reserved);
+    return launch_with_lds(attn_fwd_kernel<D, NW, false, 1>, "attn_fwd", sizeof(bf16) * 2 * (size_t)nkp * (D + 8), a.B * a.H, NW * 64, s, a, nkp,
+                           reserved);
+}
+// bytes of the unpadded swizzled images: K rows [0, kv_len), V rows up to the last row a P V step reads, and at least the
+// nkp rows the score MFMAs of the last key tile address from the start of the K image
+static size_t fwd_swizzled_bytes(int kv_len, int D) {
+    const int nkp = pad32(kv_len), tail = kv_len - (nkp - 32);
+    const int v_rows = nkp - (tail <= 16 ? 16 : 0);
+    const int rows = kv_len + v_rows > nkp ? kv_len + v_rows : nkp;
+    return sizeof(bf16) * (size_t)rows * D;
+}
+// two workgroups per CU: NW * 2 / 4 waves per SIMD
+template <int D, int NW>
+static int launch_fwd_sw(const AttnArgs& a, hipStream_t s) {
+    static bool reserved = false;
+    return launch_with_lds(attn_fwd_kernel<D, NW, true, NW * 2 / 4>, "attn_fwd", fwd_swizzled_bytes(a.kv_len, D), a.B * a.H, NW * 64, s, a,
+                           pad32(a.kv_len), reserved);
+}
+// streaming forward: NWQ query blocks per workgroup, chosen so that the blocks of a head divide evenly over its workgroups
+template <int D, int NWQ>
+static int launch_fwd_stream_n(const AttnArgs& a, int per_wg, hipStream_t s) {
+    const int nqt = (a.q_len + 31) / 32;
+    const size_t bytes = sizeof(bf16) * 2 * 2 * 64 * (size_t)(D + 8);
+    hipLaunchKernelGGL((attn_fwd_stream_kernel<D, NWQ>), dim3(a.B * a.H, (nqt + per_wg - 1) / per_wg), dim3(NWQ * 64), bytes, s, a, per_wg);
+    MMAE_CHECK_LAUNCH("attn_fwd_stream");
+    return MMAE_OK;
+}
+template <int D>
+static int launch_fwd_stream(const AttnArgs& a, hipStream_t s) {
+    const int nqt = (a.q_len + 31) / 32;
+    // 4 to 6 query blocks per workgroup with the fewest idle waves (10 blocks: 2 x 5; 18: 3 x 6; 7: 2 x 4)
+    int best = 4, best_idle = 1 << 30;
+    for (int n = 6; n >= 4; --n) {
+        const int idle = (nqt + n - 1) / n * n - nqt;
+        if (idle < best_idle) { best = n; best_idle = idle; }
+    }
+    if (best == 4) return launch_fwd_stream_n<D, 4>(a, 4, s);
+    if (best == 5) return launch_fwd_stream_n<D, 5>(a, 5, s);
+    return launch_fwd_stream_n<D, 6>(a, 6, s);
 }
 template <int D, int NW>
 static int launch_dq(const AttnArgs& a, hipStream_t s) {
@@ -772,6 +1035,8 @@ static int pick_waves(int tiles, size_t lds_bytes, int head_dim) {
 #define ATTN_BY_WAVES(launch, D, nw, a, stream)                                                    \
     ((nw) == 4 ? launch<D, 4>(a, stream) : (nw) == 8 ? launch<D, 8>(a, stream) : (nw) == 10 ? launch<D, 10>(a, stream) : launch<D, 12>(a, stream))
 
+static thread_local int g_fwd_variant = 0;  // 0 = by size, 1 = K / V of the head resident in LDS (padded rows), 2 = keys streamed in 64-key tiles, 3 = resident, swizzled rows
+extern "C" void mmae_attn_fwd_set_variant(int v) { g_fwd_variant = v; }
 static thread_local int g_bwd_variant = 0;  // 0 = by size, 1 = two kernels, 2 = one kernel whenever the head fits LDS
 extern "C" void mmae_attn_bwd_set_variant(int v) { g_bwd_variant = v; }
 
@@ -811,6 +1076,18 @@ extern "C" int mmae_attn_fwd(const void* q, long ldq, const void* k, long ldk, c
     a.o = (bf16*)o; a.ldo = ldo; a.lse = lse; a.B = B; a.H = H; a.q_len = q_len; a.kv_len = kv_len; a.scale = scale;
     int rc = check_common(a, head_dim, "attn_fwd");
     if (rc) return rc;
+    // keys streamed where the resident images do not fit the LDS at all (no length limit then)
+    const size_t resident = sizeof(bf16) * 2 * (size_t)pad32(kv_len) * (head_dim + 8);
+    if (g_fwd_variant == 2 || (g_fwd_variant != 1 && resident > (size_t)ATTN_MAX_LDS))
+        return head_dim == 64 ? launch_fwd_stream<64>(a, stream) : launch_fwd_stream<32>(a, stream);
+    // images without padding columns where only they let two workgroups share a CU
+    if ((g_fwd_variant == 3 || (g_fwd_variant == 0 && resident > (size_t)80 * 1024)) && fwd_swizzled_bytes(kv_len, head_dim) <= (size_t)80 * 1024) {
+        const int tiles = (q_len + 31) / 32;
+        // 8 waves per workgroup, 4 per SIMD with both workgroups resident (a 10-wave workgroup lands 3 + 3 + 2 + 2 on the SIMDs
+        // and the second one no longer fits beside it at more than 85 registers: measured no faster than one workgroup)
+        if (head_dim == 64) return launch_fwd_sw<64, 8>(a, stream);
+        return launch_fwd_sw<32, 8>(a, stream);
+    }
     const int nw = pick_waves((q_len + 31) / 32, sizeof(bf16) * 2 * (size_t)pad32(kv_len) * (head_dim + 8), head_dim);
     if (head_dim == 64) return ATTN_BY_WAVES(launch_fwd, 64, nw, a, stream);
     return ATTN_BY_WAVES(launch_fwd, 32, nw, a, stream);

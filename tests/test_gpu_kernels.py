@@ -297,6 +297,43 @@ def test_attention_fwd_bwd(ops, attn_bwd_variant, B, H, Nq, Nk, d):
     assert rel_err(dv.float(), back(v4, Nk)) < BF16_TOL
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,d", [(2, 16, 289, 289, 64), (1, 2, 520, 520, 32), (2, 8, 576, 289, 32), (3, 12, 99, 99, 64), (1, 2, 17, 17, 32),
+                                          (1, 4, 33, 97, 64), (1, 3, 300, 40, 32), (1, 2, 1153, 1153, 64), (1, 1, 1, 1, 32), (1, 1, 1, 50, 64),
+                                          (2, 1, 40, 1, 32), (2, 3, 128, 128, 64), (1, 2, 65, 64, 64), (1, 2, 64, 65, 32), (1, 1, 200, 161, 64)])
+@pytest.mark.parametrize("variant", [2, 3])
+def test_attention_forward_with_streamed_keys(ops, B, H, Nq, Nk, d, variant):
+    """The forward that streams the keys through LDS in 64-key tiles with a running softmax (the default where the K / V
+    images of a head exceed half of the LDS, e.g. ViT-L/16 at 384^2: 289 encoder tokens at head_dim 64; forced here for every
+    shape) against the fp32 reference and against the resident-key kernel: any key length (one call, no chunking), tails of
+    1..63 keys, query blocks that do not fill their workgroup."""
+    scale = d ** -0.5
+    if Nq == Nk:
+        qkv = _randn(B * Nq, 3 * H * d, seed=40)
+        qv, kv_, vv = qkv[:, :H * d], qkv[:, H * d:2 * H * d], qkv[:, 2 * H * d:]
+    else:
+        qv = _randn(B * Nq, H * d, seed=41)
+        kvbuf = _randn(B * Nk, 2 * H * d, seed=42)
+        kv_, vv = kvbuf[:, :H * d], kvbuf[:, H * d:]
+    L = ops._L()
+    try:
+        L.mmae_attn_fwd_set_variant(variant)
+        o, lse = ops.attn_fwd_single(qv, kv_, vv, B, H, Nq, Nk, d, scale)
+        o2, lse2 = ops.attn_fwd_single(qv, kv_, vv, B, H, Nq, Nk, d, scale)
+    finally:
+        L.mmae_attn_fwd_set_variant(0)
+    assert torch.equal(o.view(torch.int16), o2.view(torch.int16)) and torch.equal(lse, lse2)  # reproducible
+    f = lambda t, n: t.float().reshape(B, n, H, d).permute(0, 2, 1, 3)
+    oref, lref = _attn_ref(f(qv, Nq), f(kv_, Nk), f(vv, Nk), scale)
+    assert rel_err(f(o, Nq), oref) < 6e-3 and rel_err(lse, lref) < 1e-4
+    if Nk <= L.mmae_attn_max_len(d, 0):
+        L.mmae_attn_fwd_set_variant(1)
+        try:
+            o1, lse1 = ops.attn_fwd_single(qv, kv_, vv, B, H, Nq, Nk, d, scale)
+        finally:
+            L.mmae_attn_fwd_set_variant(0)
+        assert rel_err(o.float(), o1.float()) < 6e-3 and rel_err(lse, lse1) < 1e-5
+
+
 def test_attention_length_limit(ops):
     """The keys (forward, dQ) or queries (dK/dV) of one head live in LDS: the longest sequences that fit 160 KiB run in one
     call and agree with the reference, one 32-row tile more returns MMAE_ESHAPE before anything is launched; the limits are
@@ -320,16 +357,24 @@ def test_attention_length_limit(ops):
         n_bad = (1153 if d == 64 else 1025)  # ViT-L/16 384^2 without masking at head_dim 64; one row past 1024 at head_dim 32
         big = _randn(B * n_bad, 3 * H * d, seed=32)
         qb, kb, vb = big[:, :H * d], big[:, H * d:2 * H * d], big[:, 2 * H * d:]
-        with pytest.raises(_lib.MmaeError, match="LDS"):
-            ops.attn_fwd_single(qb, kb, vb, B, H, n_bad, n_bad, d, d ** -0.5)
+        lib.mmae_attn_fwd_set_variant(1)   # the resident-key forward; the default streams keys that do not fit and has no limit
+        try:
+            with pytest.raises(_lib.MmaeError, match="LDS"):
+                ops.attn_fwd_single(qb, kb, vb, B, H, n_bad, n_bad, d, d ** -0.5)
+        finally:
+            lib.mmae_attn_fwd_set_variant(0)
         ob, lb = torch.zeros(B * n_bad, H * d, dtype=torch.bfloat16, device="cuda"), torch.zeros(B, H, n_bad, device="cuda")
         with pytest.raises(_lib.MmaeError, match="LDS"):
             ops.attn_bwd_single(qb, kb, vb, ob, ob, lb, torch.zeros_like(qb), torch.zeros_like(kb), torch.zeros_like(vb), B, H, n_bad, n_bad, d,
                                 d ** -0.5)
     # just past the limit at head_dim 64 (576 rows, the next multiple of 32 after 544)
     qkv = _randn(576, 3 * 64, seed=33)
-    with pytest.raises(_lib.MmaeError, match="LDS"):
-        ops.attn_fwd_single(qkv[:, :64], qkv[:, 64:128], qkv[:, 128:], 1, 1, 576, 576, 64, 0.125)
+    lib.mmae_attn_fwd_set_variant(1)
+    try:
+        with pytest.raises(_lib.MmaeError, match="LDS"):
+            ops.attn_fwd_single(qkv[:, :64], qkv[:, 64:128], qkv[:, 128:], 1, 1, 576, 576, 64, 0.125)
+    finally:
+        lib.mmae_attn_fwd_set_variant(0)
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,d", [(2, 4, 1153, 1153, 64),   # ViT-L/16 at 384^2 without masking: 2 x 576 tokens + 1
