@@ -146,6 +146,7 @@ int mmae_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* 
  * in 64-key tiles with a running softmax (default where the resident images exceed half of the LDS; no limit on kv_len).
  * Per calling thread; for tests and tuning. */
 void mmae_attn_fwd_set_variant(int variant);
+void mmae_attn_fwd_set_one_pass(int on);
 /* Longest sequence one call takes at this head_dim (a multiple of 32; 0 for an unsupported head_dim): backward = 0: kv_len
  * of mmae_attn_fwd (q_len is not limited there); backward = 1: q_len and kv_len of mmae_attn_bwd.  Longer sequences are
  * served by the caller in chunks of keys (forward: partial outputs merged through their log-sum-exps) and of queries x

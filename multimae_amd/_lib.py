@@ -38,6 +38,7 @@ SIGNATURES = {
     "mmae_layernorm_bwd_set_variant": (_i, [_i]),
     "mmae_attn_fwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _f, _p]),
     "mmae_attn_fwd_set_variant": (None, [_i]),
+    "mmae_attn_fwd_set_one_pass": (None, [_i]),
     "mmae_attn_max_len": (_i, [_i, _i]),
     "mmae_attn_bwd_workspace_bytes": (_z, [_i, _i, _i]),
     "mmae_attn_bwd_set_variant": (None, [_i]),

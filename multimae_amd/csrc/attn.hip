@@ -159,6 +159,8 @@ __device__ __forceinline__ void stage_rows2_sw(const bf16* a, long lda, const bf
 // forward: two passes over the key tiles per 32-query block (row maximum first, then exp / P V), so only one score
 // tile is live at a time; the second Q K^T costs D/16 MFMAs per tile.
 // --------------------------------------------------------------------------------------------
+#define ONE_TAU 8.0f  // see attn_fwd_kernel<..., ONE>
+
 template <int D, bool SWZ = false>
 __device__ __forceinline__ f32x16 score_tile(const bf16* Ks, int kt, int r, int h2, const bf16x8* qf) {
     f32x16 a = zero16();
@@ -173,7 +175,7 @@ __device__ __forceinline__ f32x16 score_tile(const bf16* Ks, int kt, int r, int 
 // tile's P V steps read (16 or 32 past the last full tile; zero from kv_len on).  The last key tile's score MFMAs then read
 // K rows past kv_len out of the V image (the launcher sizes the allocation so that they stay inside it): those score rows
 // are replaced by -inf / 0 through selects before any arithmetic, as the padded layout's zero rows are.
-template <int D, int NW, bool SWZ, int WPE>
+template <int D, int NW, bool SWZ, int WPE, bool ONE>
 __global__ __launch_bounds__(NW * 64, WPE) void attn_fwd_kernel(AttnArgs p, int nkp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LDR = SWZ ? D : D + 8, KS = D / 16, DT = D / 32;
@@ -207,24 +209,26 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_fwd_kernel(AttnArgs p, int 
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
 
         float m = -INFINITY;
-        for (int kt = 0; kt < nkt; ++kt) {
-            const f32x16 a = score_tile<D, SWZ>(Ks, kt, r, h2, qf);
-            // only the last key tile has padded keys to mask (workgroup-uniform test; the vector ALU bounds these kernels)
-            if (kt == nkt - 1 && tail < 32) {
-                // accumulator registers 4g..4g+3 hold key rows 8g..8g+7 of the tile: groups past the last key are skipped
+        if (!ONE) {
+            for (int kt = 0; kt < nkt; ++kt) {
+                const f32x16 a = score_tile<D, SWZ>(Ks, kt, r, h2, qf);
+                // only the last key tile has padded keys to mask (workgroup-uniform test; the vector ALU bounds these kernels)
+                if (kt == nkt - 1 && tail < 32) {
+                    // accumulator registers 4g..4g+3 hold key rows 8g..8g+7 of the tile: groups past the last key are skipped
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (8 * g < tail) {
+                    for (int g = 0; g < 4; ++g)
+                        if (8 * g < tail) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) m = fmaxf(m, acc_row(4 * g + e, h2) < tail ? a[4 * g + e] : -INFINITY);
-                    }
-            } else {
+                            for (int e = 0; e < 4; ++e) m = fmaxf(m, acc_row(4 * g + e, h2) < tail ? a[4 * g + e] : -INFINITY);
+                        }
+                } else {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) m = fmaxf(m, a[i]);
+                    for (int i = 0; i < 16; ++i) m = fmaxf(m, a[i]);
+                }
             }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
         }
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        const float mc = -m * c;
+        float mc = -m * c;
 
         float l = 0.f;
         f32x16 oacc[DT];
@@ -232,6 +236,36 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_fwd_kernel(AttnArgs p, int 
         for (int dt = 0; dt < DT; ++dt) oacc[dt] = zero16();
         for (int kt = 0; kt < nkt; ++kt) {
             f32x16 a = score_tile<D, SWZ>(Ks, kt, r, h2, qf);
+            if (ONE) {
+                // one pass: the reference point m of the exponentials follows the row maximum lazily: it moves (and the sums
+                // so far are rescaled) only when a tile's maximum exceeds it by more than 2^ONE_TAU after scaling, so that the
+                // exponentials stay below 2^ONE_TAU; after the first tiles that is rare and the rescale is skipped wave-wide
+                float mt = -INFINITY;
+                if (kt == nkt - 1 && tail < 32) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (8 * g < tail) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) mt = fmaxf(mt, acc_row(4 * g + e, h2) < tail ? a[4 * g + e] : -INFINITY);
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) mt = fmaxf(mt, a[i]);
+                }
+                mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+                const bool move = (mt - m) * c > ONE_TAU;  // true on the first tile (m = -inf)
+                if (__builtin_amdgcn_ballot_w64(move) != 0) {
+                    const float mn = move ? mt : m;
+                    const float corr = __builtin_amdgcn_exp2f((m - mn) * c);  // 1 where m stays, 0 on the first tile
+                    m = mn;
+                    mc = -mn * c;
+                    l *= corr;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) oacc[dt][i] *= corr;
+                }
+            }
             const bool short_tail = kt == nkt - 1 && tail <= 16;  // the second k-step of P V would multiply zeros
             if (kt == nkt - 1 && tail < 32) {
 #pragma unroll
@@ -459,27 +493,34 @@ __global__ __launch_bounds__(NWQ * 64, 4) void attn_fwd_stream_kernel(AttnArgs p
 // therefore accumulates rs = rowsum(bf16(dS)) and returns dS K - rs kbar^T with kbar = mean key, i.e. the product with
 // the centred keys, which brings dQ to the level of the other bf16 roundings (0.5 %).
 // --------------------------------------------------------------------------------------------
-template <int D, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs p, int nkp) {
+// SWZ: unpadded swizzled images (see attn_fwd_kernel), V rows [0, kv_len) first, then K rows [0, nkp) with zeros from kv_len on:
+// the last key tile's dP MFMAs read V rows past kv_len out of the K image (finite values, multiplied by probabilities that are
+// exactly 0), K itself keeps its zero rows because the dS K product runs over all of the tile's rows.
+template <int D, int NW, bool SWZ, int WPE>
+__global__ __launch_bounds__(NW * 64, WPE) void attn_bwd_dq_kernel(AttnArgs p, int nkp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int LDR = D + 8, KS = D / 16, DT = D / 32;
+    constexpr int LDR = SWZ ? D : D + 8, KS = D / 16, DT = D / 32;
     constexpr bool RS_DOT2 = D == 32;  // as in attn_bwd_fused_kernel
-    bf16* Ks = (bf16*)smem;
-    bf16* Vs = Ks + nkp * LDR;
-    float* kbar = (float*)(Vs + nkp * LDR);  // [D] mean key
+    bf16* Ks = SWZ ? (bf16*)smem + p.kv_len * D : (bf16*)smem;
+    bf16* Vs = SWZ ? (bf16*)smem : Ks + nkp * LDR;
+    float* kbar = (float*)((bf16*)smem + (SWZ ? p.kv_len + nkp : 2 * nkp) * LDR);  // [D] mean key
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h2 = lane >> 5;
     const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
 
-    stage_pair<D>(p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.kv_len, nkp, Ks, Vs,
-                  tid, NW * 64);
+    if (SWZ)
+        stage_rows2_sw<D, 4>(p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.kv_len, nkp, Vs,
+                             Ks, tid, NW * 64);
+    else
+        stage_pair<D>(p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.kv_len, nkp, Ks, Vs,
+                      tid, NW * 64);
     __syncthreads();
     if (tid < D) {
         float sum = 0.f;
         if (p.mean_key) {
             sum = p.mean_key[((long)b * p.H + h) * D + tid] * (float)p.kv_len;
         } else {
-            for (int n = 0; n < p.kv_len; ++n) sum += (float)Ks[n * LDR + tid];
+            for (int n = 0; n < p.kv_len; ++n) sum += (float)Ks[SWZ ? n * D + ((((tid >> 3) ^ swz<D>(n)) << 3) | (tid & 7)) : n * LDR + tid];
         }
         kbar[tid] = sum / (float)p.kv_len;
     }
@@ -517,8 +558,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs p, int nk
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Ks, kt * 32 + r, ks, h2), qf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vs, kt * 32 + r, ks, h2), dof[ks], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16((SWZ ? row_frag_sw<D>(Ks, kt * 32 + r, ks, h2) : row_frag<D>(Ks, kt * 32 + r, ks, h2)), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16((SWZ ? row_frag_sw<D>(Vs, kt * 32 + r, ks, h2) : row_frag<D>(Vs, kt * 32 + r, ks, h2)), dof[ks], dp, 0, 0, 0);
             }
             // only the last key tile has padded keys to mask (workgroup-uniform test; the vector ALU bounds these kernels)
             if (kt == nkt - 1 && tail < 32) {
@@ -541,7 +582,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs p, int nk
                 if (RS_DOT2) rs = add_bf16x8(rs, dsf);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ks, LDR, kt * 32 + 16 * s2, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((SWZ ? tr_frag_sw<D>(Ks, kt * 32 + 16 * s2, dt * 32, lane) : tr_frag(Ks, LDR, kt * 32 + 16 * s2, dt * 32, lane)), dsf, dq[dt], 0, 0, 0);
             }
         }
         rs += __shfl_xor(rs, 32, 64);
@@ -567,20 +608,27 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs p, int nk
 // backward, kernel 2: dK, dV per 32-key tile.  Q and dO of the head live in LDS (+ lse, delta per query); the K and V
 // rows of the tile come from global memory as fragments; accumulation over the query blocks stays in registers.
 // --------------------------------------------------------------------------------------------
-template <int D, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs p, int nqp) {
+// SWZ: unpadded swizzled images, dO rows [0, q_len) first, then Q rows [0, nqp) with zeros from q_len on: padded queries have
+// zero scores and lse = +big, hence probabilities and dS that are exactly 0, and the dO rows read for them out of the Q image
+// are finite.
+template <int D, int NW, bool SWZ, int WPE>
+__global__ __launch_bounds__(NW * 64, WPE) void attn_bwd_dkv_kernel(AttnArgs p, int nqp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int LDR = D + 8, KS = D / 16, DT = D / 32;
-    bf16* Qs = (bf16*)smem;                    // [nqp][LDR]
-    bf16* dOs = Qs + nqp * LDR;                // [nqp][LDR]
-    float* lse2 = (float*)(dOs + nqp * LDR);   // [nqp]
+    constexpr int LDR = SWZ ? D : D + 8, KS = D / 16, DT = D / 32;
+    bf16* Qs = SWZ ? (bf16*)smem + p.q_len * D : (bf16*)smem;   // [nqp][LDR]
+    bf16* dOs = SWZ ? (bf16*)smem : Qs + nqp * LDR;             // [nqp][LDR]   (SWZ: [q_len][D])
+    float* lse2 = (float*)((bf16*)smem + (SWZ ? p.q_len + nqp : 2 * nqp) * LDR);   // [nqp]
     float* delta = lse2 + nqp;                 // [nqp]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h2 = lane >> 5;
     const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
 
-    stage_pair<D>(p.q + (long)b * p.q_len * p.ldq + h * D, p.ldq, p.dO + (long)b * p.q_len * p.lddo + h * D, p.lddo, p.q_len, nqp, Qs, dOs,
-                  tid, NW * 64);
+    if (SWZ)
+        stage_rows2_sw<D, 4>(p.dO + (long)b * p.q_len * p.lddo + h * D, p.lddo, p.q + (long)b * p.q_len * p.ldq + h * D, p.ldq, p.q_len, nqp, dOs,
+                             Qs, tid, NW * 64);
+    else
+        stage_pair<D>(p.q + (long)b * p.q_len * p.ldq + h * D, p.ldq, p.dO + (long)b * p.q_len * p.lddo + h * D, p.lddo, p.q_len, nqp, Qs, dOs,
+                      tid, NW * 64);
     for (int n = tid; n < nqp; n += NW * 64) {
         const bool ok = n < p.q_len;
         lse2[n] = ok ? p.lse[((long)b * p.H + h) * p.q_len + n] * LOG2E : 1e30f;
@@ -607,8 +655,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs p, int n
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Qs, qb * 32 + r, ks, h2), kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(dOs, qb * 32 + r, ks, h2), vf[ks], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16((SWZ ? row_frag_sw<D>(Qs, qb * 32 + r, ks, h2) : row_frag<D>(Qs, qb * 32 + r, ks, h2)), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16((SWZ ? row_frag_sw<D>(dOs, qb * 32 + r, ks, h2) : row_frag<D>(dOs, qb * 32 + r, ks, h2)), vf[ks], dp, 0, 0, 0);
             }
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
@@ -627,8 +675,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs p, int n
                 const bf16x8 pf = pack8(s, s2), dsf = pack8(dp, s2);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dOs, LDR, qb * 32 + 16 * s2, dt * 32, lane), pf, dv[dt], 0, 0, 0);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qs, LDR, qb * 32 + 16 * s2, dt * 32, lane), dsf, dk[dt], 0, 0, 0);
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((SWZ ? tr_frag_sw<D>(dOs, qb * 32 + 16 * s2, dt * 32, lane) : tr_frag(dOs, LDR, qb * 32 + 16 * s2, dt * 32, lane)), pf, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((SWZ ? tr_frag_sw<D>(Qs, qb * 32 + 16 * s2, dt * 32, lane) : tr_frag(Qs, LDR, qb * 32 + 16 * s2, dt * 32, lane)), dsf, dk[dt], 0, 0, 0);
                 }
             }
         }
@@ -956,12 +1004,24 @@ static int launch_with_lds(K kern, const char* name, size_t bytes, int blocks, i
 
 static inline int pad32(int n) { return (n + 31) / 32 * 32; }
 
+// Passes over the keys in the resident forward: 0 = by layout (swizzled images, i.e. long sequences: one pass with a lazily
+// moved reference point, measured 236 -> 207 us at 289 keys / head_dim 64 and 179 -> 173 us at 576 / 32; padded images: one
+// pass at head_dim 32 with 8 or more waves (196 keys: 37.0 -> 34.8 us), else two passes, row maximum first, which is faster
+// at 99 keys / head_dim 64 with 4 waves (33.6 against 36.5 us: the one-pass form needs 152 registers there)),
+// 1 = one pass, 2 = two passes
+static thread_local int g_fwd_one_pass = 0;
+extern "C" void mmae_attn_fwd_set_one_pass(int v) { g_fwd_one_pass = v; }
 template <int D, int NW>
 static int launch_fwd(const AttnArgs& a, hipStream_t s) {
     static bool reserved = false;
     const int nkp = pad32(a.kv_len);
-    return launch_with_lds(attn_fwd_kernel<D, NW, false, 1>, "attn_fwd", sizeof(bf16) * 2 * (size_t)nkp * (D + 8), a.B * a.H, NW * 64, s, a, nkp,
-                           reserved);
+    if (g_fwd_one_pass == 1 || (g_fwd_one_pass == 0 && D == 32 && NW >= 8)) {
+        static bool reserved1 = false;
+        return launch_with_lds(attn_fwd_kernel<D, NW, false, 1, true>, "attn_fwd", sizeof(bf16) * 2 * (size_t)nkp * (D + 8), a.B * a.H, NW * 64, s, a,
+                               nkp, reserved1);
+    }
+    return launch_with_lds(attn_fwd_kernel<D, NW, false, 1, false>, "attn_fwd", sizeof(bf16) * 2 * (size_t)nkp * (D + 8), a.B * a.H, NW * 64, s, a,
+                           nkp, reserved);
 }
 // bytes of the unpadded swizzled images: K rows [0, kv_len), V rows up to the last row a P V step reads, and at least the
 // nkp rows the score MFMAs of the last key tile address from the start of the K image
@@ -975,7 +1035,12 @@ static size_t fwd_swizzled_bytes(int kv_len, int D) {
 template <int D, int NW>
 static int launch_fwd_sw(const AttnArgs& a, hipStream_t s) {
     static bool reserved = false;
-    return launch_with_lds(attn_fwd_kernel<D, NW, true, NW * 2 / 4>, "attn_fwd", fwd_swizzled_bytes(a.kv_len, D), a.B * a.H, NW * 64, s, a,
+    if (g_fwd_one_pass != 2) {
+        static bool reserved1 = false;
+        return launch_with_lds(attn_fwd_kernel<D, NW, true, NW * 2 / 4, true>, "attn_fwd", fwd_swizzled_bytes(a.kv_len, D), a.B * a.H, NW * 64, s, a,
+                               pad32(a.kv_len), reserved1);
+    }
+    return launch_with_lds(attn_fwd_kernel<D, NW, true, NW * 2 / 4, false>, "attn_fwd", fwd_swizzled_bytes(a.kv_len, D), a.B * a.H, NW * 64, s, a,
                            pad32(a.kv_len), reserved);
 }
 // streaming forward: NWQ query blocks per workgroup, chosen so that the blocks of a head divide evenly over its workgroups
@@ -1004,14 +1069,30 @@ template <int D, int NW>
 static int launch_dq(const AttnArgs& a, hipStream_t s) {
     static bool reserved = false;
     const int nkp = pad32(a.kv_len);
-    return launch_with_lds(attn_bwd_dq_kernel<D, NW>, "attn_bwd_dq", sizeof(bf16) * 2 * (size_t)nkp * (D + 8) + sizeof(float) * D, a.B * a.H, NW * 64, s, a, nkp, reserved);
+    return launch_with_lds(attn_bwd_dq_kernel<D, NW, false, 1>, "attn_bwd_dq", sizeof(bf16) * 2 * (size_t)nkp * (D + 8) + sizeof(float) * D, a.B * a.H, NW * 64, s, a, nkp, reserved);
 }
 template <int D, int NW>
 static int launch_dkv(const AttnArgs& a, hipStream_t s) {
     static bool reserved = false;
     const int nqp = pad32(a.q_len);
-    return launch_with_lds(attn_bwd_dkv_kernel<D, NW>, "attn_bwd_dkv", sizeof(bf16) * 2 * (size_t)nqp * (D + 8) + sizeof(float) * 2 * nqp,
+    return launch_with_lds(attn_bwd_dkv_kernel<D, NW, false, 1>, "attn_bwd_dkv", sizeof(bf16) * 2 * (size_t)nqp * (D + 8) + sizeof(float) * 2 * nqp,
                            a.B * a.H, NW * 64, s, a, nqp, reserved);
+}
+
+// swizzled images, two workgroups per CU
+static size_t dq_swizzled_bytes(int kv_len, int D) { return sizeof(bf16) * (size_t)(kv_len + pad32(kv_len)) * D + sizeof(float) * D; }
+static size_t dkv_swizzled_bytes(int q_len, int D) { return sizeof(bf16) * (size_t)(q_len + pad32(q_len)) * D + sizeof(float) * 2 * pad32(q_len); }
+template <int D, int NW>
+static int launch_dq_sw(const AttnArgs& a, hipStream_t s) {
+    static bool reserved = false;
+    return launch_with_lds(attn_bwd_dq_kernel<D, NW, true, NW * 2 / 4>, "attn_bwd_dq", dq_swizzled_bytes(a.kv_len, D), a.B * a.H, NW * 64, s, a,
+                           pad32(a.kv_len), reserved);
+}
+template <int D, int NW>
+static int launch_dkv_sw(const AttnArgs& a, hipStream_t s) {
+    static bool reserved = false;
+    return launch_with_lds(attn_bwd_dkv_kernel<D, NW, true, NW * 2 / 4>, "attn_bwd_dkv", dkv_swizzled_bytes(a.q_len, D), a.B * a.H, NW * 64, s, a,
+                           pad32(a.q_len), reserved);
 }
 
 // Waves per workgroup for `tiles` 32-row work items (query tiles of the forward and dQ kernels, key tiles of the dK / dV
@@ -1037,7 +1118,7 @@ static int pick_waves(int tiles, size_t lds_bytes, int head_dim) {
 
 static thread_local int g_fwd_variant = 0;  // 0 = by size, 1 = K / V of the head resident in LDS (padded rows), 2 = keys streamed in 64-key tiles, 3 = resident, swizzled rows
 extern "C" void mmae_attn_fwd_set_variant(int v) { g_fwd_variant = v; }
-static thread_local int g_bwd_variant = 0;  // 0 = by size, 1 = two kernels, 2 = one kernel whenever the head fits LDS
+static thread_local int g_bwd_variant = 0;  // 0 = by size, 1 = two kernels (padded images), 2 = one kernel whenever the head fits LDS, 3 = two kernels, swizzled images wherever they fit
 extern "C" void mmae_attn_bwd_set_variant(int v) { g_bwd_variant = v; }
 
 static size_t fused_lds_bytes(const AttnArgs& a, int D) {
@@ -1137,14 +1218,23 @@ extern "C" int mmae_attn_bwd_chunk(const void* q, long ldq, const void* k, long 
     // one kernel when Q, dO, K, V of a head fit LDS twice per CU (two blocks keep 16 waves resident)
     if (g_bwd_variant != 1 && fused_lds_bytes(a, head_dim) <= (g_bwd_variant == 2 ? (size_t)ATTN_MAX_LDS : (size_t)80 * 1024))
         return head_dim == 64 ? launch_fused<64, 8>(a, stream) : launch_fused<32, 8>(a, stream);
-    const int nw_q = pick_waves((q_len + 31) / 32, sizeof(bf16) * 2 * (size_t)pad32(kv_len) * (head_dim + 8), head_dim);   // dQ: K, V in LDS
-    const int nw_k = pick_waves((kv_len + 31) / 32, sizeof(bf16) * 2 * (size_t)pad32(q_len) * (head_dim + 8), head_dim);   // dK / dV: Q, dO in LDS
+    const size_t dq_padded = sizeof(bf16) * 2 * (size_t)pad32(kv_len) * (head_dim + 8), dkv_padded = sizeof(bf16) * 2 * (size_t)pad32(q_len) * (head_dim + 8);
+    const int nw_q = pick_waves((q_len + 31) / 32, dq_padded, head_dim);   // dQ: K, V in LDS
+    const int nw_k = pick_waves((kv_len + 31) / 32, dkv_padded, head_dim);   // dK / dV: Q, dO in LDS
+    // unpadded swizzled images where only they let two workgroups share a CU (variant 3: wherever they fit half the LDS).
+    // By size at head_dim 32 only (576 rows: dQ + dK / dV 667 -> 491 us; 576 queries x 289 keys: 405 -> 322 us): at head_dim 64
+    // these kernels need 157 / 166 registers, two 8-wave workgroups leave them 128 and the spills cost more than the second
+    // workgroup brings (289 rows: 720 -> 1070 us; with 6 waves and 168 registers 772 us).
+    const size_t half = (size_t)80 * 1024;
+    const bool by_size = g_bwd_variant == 0 && head_dim == 32;
+    const bool sw_q = (g_bwd_variant == 3 || (by_size && dq_padded + sizeof(float) * head_dim > half)) && dq_swizzled_bytes(kv_len, head_dim) <= half;
+    const bool sw_k = (g_bwd_variant == 3 || (by_size && dkv_padded + sizeof(float) * 2 * pad32(q_len) > half)) && dkv_swizzled_bytes(q_len, head_dim) <= half;
     if (head_dim == 64) {
-        rc = ATTN_BY_WAVES(launch_dq, 64, nw_q, a, stream);
+        rc = sw_q ? launch_dq_sw<64, 8>(a, stream) : ATTN_BY_WAVES(launch_dq, 64, nw_q, a, stream);
         if (rc) return rc;
-        return ATTN_BY_WAVES(launch_dkv, 64, nw_k, a, stream);
+        return sw_k ? launch_dkv_sw<64, 8>(a, stream) : ATTN_BY_WAVES(launch_dkv, 64, nw_k, a, stream);
     }
-    rc = ATTN_BY_WAVES(launch_dq, 32, nw_q, a, stream);
+    rc = sw_q ? launch_dq_sw<32, 8>(a, stream) : ATTN_BY_WAVES(launch_dq, 32, nw_q, a, stream);
     if (rc) return rc;
-    return ATTN_BY_WAVES(launch_dkv, 32, nw_k, a, stream);
+    return sw_k ? launch_dkv_sw<32, 8>(a, stream) : ATTN_BY_WAVES(launch_dkv, 32, nw_k, a, stream);
 }

@@ -20,15 +20,19 @@ if __name__ == "__main__":
         res = []
         for variant in (1, 2, 3, 0):
             L.mmae_attn_fwd_set_variant(variant)
+            L.mmae_attn_fwd_set_one_pass(2)
             t = timeit(lambda: ops.attn_fwd(q, k_, v, B, H, nq, nk, d, d ** -0.5))
-            res.append(f"{t*1e6:7.1f} us {fl/t/1e12:6.1f} TF")
+            L.mmae_attn_fwd_set_one_pass(1)
+            t1 = timeit(lambda: ops.attn_fwd(q, k_, v, B, H, nq, nk, d, d ** -0.5))
+            L.mmae_attn_fwd_set_one_pass(0)
+            res.append(f"{t*1e6:6.1f} / {t1*1e6:6.1f} us {fl/t/1e12:5.0f} / {fl/t1/1e12:5.0f} TF")
         L.mmae_attn_fwd_set_variant(0)
         o, lse = ops.attn_fwd(q, k_, v, B, H, nq, nk, d, d ** -0.5)
         do = r(B * nq, H * d)
         bres = []
-        for variant in ((1, 2, 0) if hasattr(L, "mmae_attn_bwd_stream_probe") else (0,)):
+        for variant in (1, 3, 0):
             L.mmae_attn_bwd_set_variant(variant)
             t2 = timeit(lambda: ops.attn_bwd(q, k_, v, o, do, lse, dq, dk, dv, B, H, nq, nk, d, d ** -0.5))
             bres.append(f"{t2*1e6:7.1f} us {2*fl/t2/1e12:6.1f} TF")
         L.mmae_attn_bwd_set_variant(0)
-        print(f"attn {name:12s}: fwd resident {res[0]} | streamed {res[1]} | swizzled {res[2]} | auto {res[3]} || bwd {' | '.join(bres)}")
+        print(f"attn {name:12s}: fwd resident {res[0]} | streamed {res[1]} | swizzled {res[2]} | auto {res[3]} || bwd padded / swizzled / auto {' | '.join(bres)}")

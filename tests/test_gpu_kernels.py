@@ -250,7 +250,7 @@ def _attn_ref(q, k, v, scale):
     return torch.einsum("bhqk,bhkd->bhqd", p, v), torch.logsumexp(s, -1)
 
 
-@pytest.fixture(params=[1, 2], ids=["two_kernels", "fused"])
+@pytest.fixture(params=[1, 2, 3], ids=["two_kernels", "fused", "two_kernels_swizzled"])
 def attn_bwd_variant(request, ops):
     ops._L().mmae_attn_bwd_set_variant(request.param)
     yield request.param
@@ -259,7 +259,7 @@ def attn_bwd_variant(request, ops):
 
 @pytest.mark.parametrize("B,H,Nq,Nk,d", [(3, 12, 99, 99, 64), (2, 8, 196, 196, 32), (2, 8, 196, 99, 32), (1, 2, 17, 17, 32),
                                           (2, 3, 128, 128, 64), (1, 4, 33, 97, 64), (2, 8, 197, 197, 32), (1, 2, 289, 289, 64), (1, 3, 300, 40, 32),
-                                          (1, 2, 250, 250, 64), (1, 2, 520, 520, 32),
+                                          (1, 2, 250, 250, 64), (1, 2, 520, 520, 32), (2, 8, 576, 289, 32), (1, 3, 290, 305, 64),
                                           (1, 1, 1, 1, 32), (1, 1, 1, 50, 64), (2, 1, 40, 1, 32), (3, 2, 2, 3, 64)])  # a single query / key
 def test_attention_fwd_bwd(ops, attn_bwd_variant, B, H, Nq, Nk, d):
     scale = d ** -0.5
@@ -300,12 +300,13 @@ def test_attention_fwd_bwd(ops, attn_bwd_variant, B, H, Nq, Nk, d):
 @pytest.mark.parametrize("B,H,Nq,Nk,d", [(2, 16, 289, 289, 64), (1, 2, 520, 520, 32), (2, 8, 576, 289, 32), (3, 12, 99, 99, 64), (1, 2, 17, 17, 32),
                                           (1, 4, 33, 97, 64), (1, 3, 300, 40, 32), (1, 2, 1153, 1153, 64), (1, 1, 1, 1, 32), (1, 1, 1, 50, 64),
                                           (2, 1, 40, 1, 32), (2, 3, 128, 128, 64), (1, 2, 65, 64, 64), (1, 2, 64, 65, 32), (1, 1, 200, 161, 64)])
-@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("variant", [2, 3, 10, 23])
 def test_attention_forward_with_streamed_keys(ops, B, H, Nq, Nk, d, variant):
-    """The forward that streams the keys through LDS in 64-key tiles with a running softmax (the default where the K / V
-    images of a head exceed half of the LDS, e.g. ViT-L/16 at 384^2: 289 encoder tokens at head_dim 64; forced here for every
-    shape) against the fp32 reference and against the resident-key kernel: any key length (one call, no chunking), tails of
-    1..63 keys, query blocks that do not fill their workgroup."""
+    """The other forms of the forward, forced for every shape, against the fp32 reference and against the padded two-pass
+    resident kernel: 2 = keys streamed through LDS in 64-key tiles with a running softmax (the default where a head's K / V
+    do not fit the LDS: any key length in one call); 3 = resident K / V in unpadded swizzled images, one pass (the default
+    where only that lets two workgroups share a CU, e.g. ViT-L/16 at 384^2: 289 encoder tokens at head_dim 64); 10 = padded
+    images, one pass; 23 = swizzled images, two passes.  Tails of 1..63 keys, query blocks that do not fill their workgroup."""
     scale = d ** -0.5
     if Nq == Nk:
         qkv = _randn(B * Nq, 3 * H * d, seed=40)
@@ -316,11 +317,13 @@ def test_attention_forward_with_streamed_keys(ops, B, H, Nq, Nk, d, variant):
         kv_, vv = kvbuf[:, :H * d], kvbuf[:, H * d:]
     L = ops._L()
     try:
-        L.mmae_attn_fwd_set_variant(variant)
+        L.mmae_attn_fwd_set_variant(variant % 10)
+        L.mmae_attn_fwd_set_one_pass(variant // 10)
         o, lse = ops.attn_fwd_single(qv, kv_, vv, B, H, Nq, Nk, d, scale)
         o2, lse2 = ops.attn_fwd_single(qv, kv_, vv, B, H, Nq, Nk, d, scale)
     finally:
         L.mmae_attn_fwd_set_variant(0)
+        L.mmae_attn_fwd_set_one_pass(0)
     assert torch.equal(o.view(torch.int16), o2.view(torch.int16)) and torch.equal(lse, lse2)  # reproducible
     f = lambda t, n: t.float().reshape(B, n, H, d).permute(0, 2, 1, 3)
     oref, lref = _attn_ref(f(qv, Nq), f(kv_, Nk), f(vv, Nk), scale)
@@ -332,6 +335,32 @@ def test_attention_forward_with_streamed_keys(ops, B, H, Nq, Nk, d, variant):
         finally:
             L.mmae_attn_fwd_set_variant(0)
         assert rel_err(o.float(), o1.float()) < 6e-3 and rel_err(lse, lse1) < 1e-5
+
+
+@pytest.mark.parametrize("variant", [2, 3, 10])
+@pytest.mark.parametrize("d", [32, 64])
+def test_attention_forward_one_pass_follows_a_growing_maximum(ops, d, variant):
+    """One-pass forms: the reference point of the exponentials has to move when later keys score far above the earlier ones
+    (here the keys grow 6x along the sequence and the scores reach +-60), and the sums so far are rescaled each time."""
+    B, H, N = 2, 3, 289
+    qkv = _randn(B * N, 3 * H * d, seed=50).float()
+    grow = (1.0 + 5.0 * torch.arange(N, device="cuda") / N).repeat(B)[:, None]
+    qkv[:, H * d:2 * H * d] *= grow * 1.5
+    qkv[:, :H * d] *= 2.0
+    qkv = qkv.to(torch.bfloat16)
+    q, k, v = qkv[:, :H * d], qkv[:, H * d:2 * H * d], qkv[:, 2 * H * d:]
+    L = ops._L()
+    try:
+        L.mmae_attn_fwd_set_variant(variant % 10)
+        L.mmae_attn_fwd_set_one_pass(1)
+        o, lse = ops.attn_fwd_single(q, k, v, B, H, N, N, d, d ** -0.5)
+    finally:
+        L.mmae_attn_fwd_set_variant(0)
+        L.mmae_attn_fwd_set_one_pass(0)
+    f = lambda t: t.float().reshape(B, N, H, d).permute(0, 2, 1, 3)
+    oref, lref = _attn_ref(f(q), f(k), f(v), d ** -0.5)
+    assert lref.abs().max() > 20  # the case is what it claims to be
+    assert rel_err(f(o), oref) < 6e-3 and rel_err(lse, lref) < 1e-4
 
 
 def test_attention_length_limit(ops):
