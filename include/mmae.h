@@ -133,24 +133,29 @@ int mmae_layernorm_param_reduce(const void* workspace, size_t workspace_bytes, i
 /* ---- attention (multimae/multimae_utils.py:200-204 and :240-244) ----------------------------
  * softmax(q k^T * scale) v per (batch, head) without materialising the scores.  q/k/v/o rows are
  * addressed as base + (b*len + i)*ld + h*head_dim, so the packed [B,N,3,H,d] qkv buffer and the
- * [B,M,2,H,d] kv buffer are read in place.  head_dim in {32, 64}.  The rows of one head that a kernel keeps in
- * LDS (K,V for fwd and the dQ kernel; Q,dO and two floats per query for the dK/dV kernel), padded to a multiple of 32
- * rows of head_dim + 8 elements, must fit 160 KiB: kv_len <= 544 at head_dim 64 and <= 1024 at head_dim 32 for fwd;
- * for bwd also q_len <= 544 at head_dim 64 and <= 960 at head_dim 32.  Longer sequences return MMAE_ESHAPE.
+ * [B,M,2,H,d] kv buffer are read in place.  head_dim in {32, 64}.  fwd takes any kv_len: the K / V rows of a head stay
+ * in LDS where they fit 160 KiB (padded to a multiple of 32 rows of head_dim + 8 elements, or unpadded and swizzled where
+ * only that leaves room for a second workgroup on the CU) and stream through it in 64-key tiles beyond.  bwd keeps K,V
+ * (dQ kernel) and Q,dO plus two floats per query (dK/dV kernel) of a head in LDS: q_len and kv_len <= 544 at head_dim 64
+ * and <= 960 at head_dim 32 per call (mmae_attn_max_len), longer sequences return MMAE_ESHAPE (callers chunk them,
+ * mmae_attn_bwd_chunk).
  * fwd also writes lse[B,H,q_len] (f32, natural log) for the backward.  bwd = one kernel per (batch, head) with Q, dO, K, V
  * in LDS when two such blocks fit a CU (the pretraining lengths), else two kernels (dQ per query block; dK,dV per key
  * tile); accumulation in registers, no atomics; workspace holds rowsum(dO*O) [B,H,q_len] f32 for the two-kernel form. */
 int mmae_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
                   float* lse, int B, int H, int q_len, int kv_len, int head_dim, float scale, mmae_stream_t stream);
-/* Kernel choice for mmae_attn_fwd: 0 = by size (default), 1 = K / V of a head resident in LDS, 2 = keys streamed through LDS
- * in 64-key tiles with a running softmax (default where the resident images exceed half of the LDS; no limit on kv_len).
- * Per calling thread; for tests and tuning. */
+/* Kernel choice for mmae_attn_fwd: 0 = by size (default), 1 = K / V of a head resident in LDS in padded images (kv_len up
+ * to mmae_attn_max_len(head_dim, 0), MMAE_ESHAPE beyond), 2 = keys streamed through LDS in 64-key tiles with a running softmax
+ * (default where the resident images do not fit), 3 = resident in unpadded swizzled images (default where the padded images
+ * take more than half of the LDS and these do not).  mmae_attn_fwd_set_one_pass: passes of the resident kernels over the keys,
+ * 0 = by layout (default), 1 = one pass with a lazily moved reference point of the exponentials, 2 = two passes (row maximum
+ * first).  Per calling thread; for tests and tuning. */
 void mmae_attn_fwd_set_variant(int variant);
 void mmae_attn_fwd_set_one_pass(int on);
-/* Longest sequence one call takes at this head_dim (a multiple of 32; 0 for an unsupported head_dim): backward = 0: kv_len
- * of mmae_attn_fwd (q_len is not limited there); backward = 1: q_len and kv_len of mmae_attn_bwd.  Longer sequences are
- * served by the caller in chunks of keys (forward: partial outputs merged through their log-sum-exps) and of queries x
- * keys (backward: partial gradients summed), as multimae_amd/ops.py does. */
+/* Longest sequence the LDS-resident kernels take at this head_dim (a multiple of 32; 0 for an unsupported head_dim):
+ * backward = 0: kv_len up to which mmae_attn_fwd keeps K / V resident (it streams them beyond; q_len is not limited);
+ * backward = 1: q_len and kv_len of one mmae_attn_bwd call.  Longer backward sequences are served by the caller in chunks of
+ * queries x keys (partial gradients summed), as multimae_amd/ops.py does. */
 int mmae_attn_max_len(int head_dim, int backward);
 size_t mmae_attn_bwd_workspace_bytes(int B, int H, int q_len);
 int mmae_attn_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* o, long ldo,
@@ -167,8 +172,9 @@ int mmae_attn_bwd_chunk(const void* q, long ldq, const void* k, long ldk, const 
                         const void* d_o, long lddo, const float* lse, const float* mean_key, void* dq, long lddq, void* dk,
                         long lddk, void* dv, long lddv, int B, int H, int q_len, int kv_len, int head_dim, float scale,
                         void* workspace, size_t workspace_bytes, mmae_stream_t stream);
-/* Kernel choice for mmae_attn_bwd: 0 = by size (default), 1 = two kernels, 2 = one kernel whenever Q, dO, K, V of a head
- * fit the 160 KiB LDS.  Per calling thread; for tests and tuning. */
+/* Kernel choice for mmae_attn_bwd: 0 = by size (default), 1 = two kernels with padded LDS images, 2 = one kernel whenever
+ * Q, dO, K, V of a head fit the 160 KiB LDS, 3 = two kernels with unpadded swizzled images wherever those fit half of the LDS
+ * (the default at head_dim 32 where the padded images take more than half).  Per calling thread; for tests and tuning. */
 void mmae_attn_bwd_set_variant(int variant);
 
 /* ---- masking (multimae/multimae.py:218-253) --------------------------------------------------

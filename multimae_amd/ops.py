@@ -313,21 +313,9 @@ def _seq_rows(t: torch.Tensor, B: int, n: int, s: int, e: int) -> torch.Tensor:
 def attn_fwd(q, k, v, B, H, q_len, kv_len, head_dim, scale):
     """softmax(q k^T scale) v per (sample, head).  q: [B*q_len, >=H*d] view, k/v: [B*kv_len, ...] views (row-strided slices
     of packed projections).  Returns (o [B*q_len, H*d] bf16, lse [B,H,q_len] f32).
-    One kernel call keeps the keys and values of a head in LDS (attn_fwd_single); longer key sequences run as one call per
-    chunk of keys, and the partial outputs are merged through their log-sum-exps: o = sum_c exp(lse_c - lse) o_c."""
-    limit = _L().mmae_attn_max_len(head_dim, 0)
-    if kv_len <= limit or limit <= 0:
-        return attn_fwd_single(q, k, v, B, H, q_len, kv_len, head_dim, scale)
-    outs, lses = [], []
-    for s, e in _seq_chunks(kv_len, limit):
-        o_c, lse_c = attn_fwd_single(q, _seq_rows(k, B, kv_len, s, e), _seq_rows(v, B, kv_len, s, e), B, H, q_len, e - s, head_dim, scale)
-        outs.append(o_c)
-        lses.append(lse_c)
-    lse_all = torch.stack(lses)                                 # [chunks, B, H, q_len]
-    lse = torch.logsumexp(lse_all, dim=0)
-    w = torch.exp(lse_all - lse).permute(0, 1, 3, 2).unsqueeze(-1)  # [chunks, B, q_len, H, 1]
-    o = sum(o_c.view(B, q_len, H, head_dim).float() * w_c for o_c, w_c in zip(outs, w))
-    return o.to(BF16).view(B * q_len, H * head_dim), lse
+    One kernel call for any length: the keys and values of a head stay in LDS where they fit (up to
+    mmae_attn_max_len(head_dim, 0) keys) and stream through it in 64-key tiles with a running softmax beyond."""
+    return attn_fwd_single(q, k, v, B, H, q_len, kv_len, head_dim, scale)
 
 
 def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, q_len, kv_len, head_dim, scale):
@@ -358,7 +346,7 @@ def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, q_len, kv_len, head_dim, sc
 
 
 def attn_fwd_single(q, k, v, B, H, q_len, kv_len, head_dim, scale):
-    """One mmae_attn_fwd call (kv_len up to mmae_attn_max_len(head_dim, 0)); arguments and result as attn_fwd."""
+    """One mmae_attn_fwd call; arguments and result as attn_fwd."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _req(t, BF16, f"attn_fwd {n}", contiguous=False)
     o = torch.empty((B * q_len, H * head_dim), dtype=BF16, device=q.device)

@@ -410,8 +410,8 @@ def test_attention_length_limit(ops):
                                          (1, 2, 700, 1300, 32),    # cross-attention: only the keys are chunked
                                          (1, 2, 1000, 99, 32)])    # backward: only the queries are chunked
 def test_attention_beyond_one_call_runs_in_chunks(ops, B, H, Nq, Nk, d):
-    """Sequences longer than one kernel call takes: chunks of keys merged through their log-sum-exps (forward), chunks of
-    queries x keys with summed partial gradients (backward); same tolerances as the single call."""
+    """Sequences longer than the LDS-resident kernels take: the forward streams the keys (one call), the backward runs as chunks
+    of queries x keys with summed partial gradients; same tolerances as the single call."""
     scale = d ** -0.5
     if Nq == Nk:
         qkv = _randn(B * Nq, 3 * H * d, seed=40)
