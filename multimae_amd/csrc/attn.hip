@@ -515,14 +515,38 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_bwd_dq_kernel(AttnArgs p, i
         stage_pair<D>(p.k + (long)b * p.kv_len * p.ldk + h * D, p.ldk, p.v + (long)b * p.kv_len * p.ldv + h * D, p.ldv, p.kv_len, nkp, Ks, Vs,
                       tid, NW * 64);
     __syncthreads();
-    if (tid < D) {
-        float sum = 0.f;
-        if (p.mean_key) {
-            sum = p.mean_key[((long)b * p.H + h) * D + tid] * (float)p.kv_len;
-        } else {
-            for (int n = 0; n < p.kv_len; ++n) sum += (float)Ks[SWZ ? n * D + ((((tid >> 3) ^ swz<D>(n)) << 3) | (tid & 7)) : n * LDR + tid];
+    if (p.mean_key) {
+        if (tid < D) kbar[tid] = p.mean_key[((long)b * p.H + h) * D + tid];
+    } else {
+        // mean key: every wave sums the rows n = wave * RL + (lane / CH) (mod NW * RL) of its lanes' 8-column chunks, folds the
+        // RL row lanes together, and the NW per-wave sums are added in wave order (one thread walking the 289 rows of a ViT-L
+        // head kept the other waves at the barrier for a twentieth of the workgroup's life: dQ + dK / dV 715 -> 680 us)
+        constexpr int CH = D / 8, RL = 64 / CH;
+        float* part = kbar + D;  // [NW][D]
+        float acc8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc8[e] = 0.f;
+        const int ch = lane % CH;
+        for (int n = wave * RL + lane / CH; n < p.kv_len; n += NW * RL) {
+            const bf16x8 kv = *(const bf16x8*)(Ks + (SWZ ? n * D + ((ch ^ swz<D>(n)) << 3) : n * LDR + ch * 8));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc8[e] += (float)kv[e];
         }
-        kbar[tid] = sum / (float)p.kv_len;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int off = CH; off < 64; off <<= 1) acc8[e] += __shfl_xor(acc8[e], off, 64);
+        if (lane < CH) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part[wave * D + ch * 8 + e] = acc8[e];
+        }
+        __syncthreads();
+        if (tid < D) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += part[w * D + tid];
+            kbar[tid] = sum / (float)p.kv_len;
+        }
     }
     __syncthreads();
 
@@ -1069,7 +1093,7 @@ template <int D, int NW>
 static int launch_dq(const AttnArgs& a, hipStream_t s) {
     static bool reserved = false;
     const int nkp = pad32(a.kv_len);
-    return launch_with_lds(attn_bwd_dq_kernel<D, NW, false, 1>, "attn_bwd_dq", sizeof(bf16) * 2 * (size_t)nkp * (D + 8) + sizeof(float) * D, a.B * a.H, NW * 64, s, a, nkp, reserved);
+    return launch_with_lds(attn_bwd_dq_kernel<D, NW, false, 1>, "attn_bwd_dq", sizeof(bf16) * 2 * (size_t)nkp * (D + 8) + sizeof(float) * D * (1 + NW), a.B * a.H, NW * 64, s, a, nkp, reserved);
 }
 template <int D, int NW>
 static int launch_dkv(const AttnArgs& a, hipStream_t s) {
@@ -1080,7 +1104,7 @@ static int launch_dkv(const AttnArgs& a, hipStream_t s) {
 }
 
 // swizzled images, two workgroups per CU
-static size_t dq_swizzled_bytes(int kv_len, int D) { return sizeof(bf16) * (size_t)(kv_len + pad32(kv_len)) * D + sizeof(float) * D; }
+static size_t dq_swizzled_bytes(int kv_len, int D) { return sizeof(bf16) * (size_t)(kv_len + pad32(kv_len)) * D + sizeof(float) * D * (1 + 8); }  // 8 waves
 static size_t dkv_swizzled_bytes(int q_len, int D) { return sizeof(bf16) * (size_t)(q_len + pad32(q_len)) * D + sizeof(float) * 2 * pad32(q_len); }
 template <int D, int NW>
 static int launch_dq_sw(const AttnArgs& a, hipStream_t s) {
@@ -1177,7 +1201,7 @@ extern "C" int mmae_attn_fwd(const void* q, long ldq, const void* k, long ldk, c
 extern "C" int mmae_attn_max_len(int head_dim, int backward) {
     if (head_dim != 32 && head_dim != 64) return 0;
     const size_t row = sizeof(bf16) * 2 * (size_t)(head_dim + 8);  // a K row and a V row (or a Q row and a dO row) of the LDS images
-    const int kv = (int)((ATTN_MAX_LDS - (backward ? sizeof(float) * head_dim : 0)) / row) / 32 * 32;  // attn_fwd / attn_bwd_dq
+    const int kv = (int)((ATTN_MAX_LDS - (backward ? sizeof(float) * head_dim * (1 + 12) : 0)) / row) / 32 * 32;  // attn_fwd / attn_bwd_dq (mean key + up to 12 per-wave sums)
     if (!backward) return kv;
     const int q = (int)(ATTN_MAX_LDS / (row + 2 * sizeof(float))) / 32 * 32;                            // attn_bwd_dkv
     return q < kv ? q : kv;
@@ -1227,7 +1251,7 @@ extern "C" int mmae_attn_bwd_chunk(const void* q, long ldq, const void* k, long 
     // workgroup brings (289 rows: 720 -> 1070 us; with 6 waves and 168 registers 772 us).
     const size_t half = (size_t)80 * 1024;
     const bool by_size = g_bwd_variant == 0 && head_dim == 32;
-    const bool sw_q = (g_bwd_variant == 3 || (by_size && dq_padded + sizeof(float) * head_dim > half)) && dq_swizzled_bytes(kv_len, head_dim) <= half;
+    const bool sw_q = (g_bwd_variant == 3 || (by_size && dq_padded + sizeof(float) * head_dim * (1 + nw_q) > half)) && dq_swizzled_bytes(kv_len, head_dim) <= half;
     const bool sw_k = (g_bwd_variant == 3 || (by_size && dkv_padded + sizeof(float) * 2 * pad32(q_len) > half)) && dkv_swizzled_bytes(q_len, head_dim) <= half;
     if (head_dim == 64) {
         rc = sw_q ? launch_dq_sw<64, 8>(a, stream) : ATTN_BY_WAVES(launch_dq, 64, nw_q, a, stream);

@@ -40,11 +40,15 @@ def trunc_normal_(tensor, mean=0.0, std=1.0, a=-2.0, b=2.0):
     return tensor
 
 
-def _no_attn_drop(module: nn.Module):
-    """Dropout on the attention probabilities would have to act inside the attention kernel, which keeps them in
-    registers: not implemented for training (in eval mode every dropout is the identity, as in the reference)."""
-    if module.training and module.attn_drop:
-        raise NotImplementedError(f"attn_drop={module.attn_drop} in training mode: the attention kernel has no dropout on its probabilities")
+def _attn_core_with_dropout(q, k, v, scale: float, p: float):
+    """softmax(q k^T scale) -> dropout -> @ v with the probabilities materialised, q [B,H,Nq,d], k / v [B,H,Nk,d] fp32
+    (reference: multimae/multimae_utils.py:200-204 and :240-244 with attn_drop > 0 in training mode).  The attention kernels
+    keep the probabilities in registers and have no dropout, so this setting (0 in every pretraining configuration) runs
+    the score and value products as plain batched library products around torch's softmax and dropout, between the same
+    projection kernels; one F.dropout call on the [B,H,Nq,Nk] probabilities, as in the reference."""
+    attn = (q @ k.transpose(-2, -1)) * scale
+    attn = F.dropout(attn.softmax(dim=-1), p, True)
+    return attn @ v
 
 
 def drop_path(x, drop_prob: float = 0.0, training: bool = False):
@@ -106,8 +110,14 @@ class Attention(nn.Module):
         self.attn_drop, self.proj_drop = attn_drop, proj_drop
 
     def forward(self, x):
-        _no_attn_drop(self)
-        y = Fn.AttentionFn.apply(x, self.num_heads, self.qkv.weight, _bias_or_zeros(self.qkv), self.proj.weight, self.proj.bias)
+        if self.training and self.attn_drop:
+            B, N, D = x.shape
+            qkv = Fn.LinearFn.apply(x, self.qkv.weight, _bias_or_zeros(self.qkv))
+            q, k, v = qkv.reshape(B, N, 3, self.num_heads, D // self.num_heads).permute(2, 0, 3, 1, 4).unbind(0)
+            y = _attn_core_with_dropout(q, k, v, self.scale, self.attn_drop).transpose(1, 2).reshape(B, N, D)
+            y = Fn.LinearFn.apply(y, self.proj.weight, self.proj.bias)
+        else:
+            y = Fn.AttentionFn.apply(x, self.num_heads, self.qkv.weight, _bias_or_zeros(self.qkv), self.proj.weight, self.proj.bias)
         return F.dropout(y, self.proj_drop, True) if self.training and self.proj_drop else y
 
 
@@ -124,7 +134,14 @@ class CrossAttention(nn.Module):
         self.attn_drop, self.proj_drop = attn_drop, proj_drop
 
     def forward(self, x, context):
-        _no_attn_drop(self)
+        if self.training and self.attn_drop:
+            B, N, D = x.shape
+            M, H = context.shape[1], self.num_heads
+            q = Fn.LinearFn.apply(x, self.q.weight, _bias_or_zeros(self.q)).reshape(B, N, H, D // H).permute(0, 2, 1, 3)
+            k, v = Fn.LinearFn.apply(context, self.kv.weight, _bias_or_zeros(self.kv)).reshape(B, M, 2, H, D // H).permute(2, 0, 3, 1, 4).unbind(0)
+            y = _attn_core_with_dropout(q, k, v, self.scale, self.attn_drop).transpose(1, 2).reshape(B, N, D)
+            y = Fn.LinearFn.apply(y, self.proj.weight, self.proj.bias)
+            return F.dropout(y, self.proj_drop, True) if self.proj_drop else y
         y = Fn.CrossAttentionFn.apply(x, context, self.num_heads, self.q.weight, _bias_or_zeros(self.q), self.kv.weight,
                                       _bias_or_zeros(self.kv), self.proj.weight, self.proj.bias)
         return F.dropout(y, self.proj_drop, True) if self.training and self.proj_drop else y

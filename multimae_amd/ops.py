@@ -605,7 +605,7 @@ def standardize_depth(depth: torch.Tensor, lo_frac: float = 0.1, hi_frac: float 
     out = torch.empty_like(depth) if out is None else _req(out, F32, "standardize_depth out")
     if B:
         # algorithmic bytes: the map read once and written once (the select's further sweeps of a sample are served by L2)
-        with _Timed("standardize_depth", 0.0, "depth_standardize_kernel", nbytes=8 * depth.numel()):
+        with _Timed("standardize_depth", 0.0, "depth_standardize", nbytes=8 * depth.numel()):
             _lib.check(_L().mmae_standardize_depth(_ptr(depth), _ptr(out), B, depth.numel() // B, lo_frac, hi_frac, eps, _stream()),
                        "standardize_depth")
     return out

@@ -84,7 +84,7 @@ def test_module_option_vs_reference_golden(case, monkeypatch):
 def test_dropout_settings_are_the_identity_in_eval_mode_and_drop_in_training_mode():
     """drop_rate acts on the projections' outputs (the reference's proj_drop / Mlp.drop): eval mode equals the model
     without dropout bitwise; training mode zeroes about drop_rate of a block's branch outputs; dropout on the attention
-    probabilities is refused in training mode only."""
+    probabilities runs through the materialised form (next test)."""
     import multimae_amd as M
     torch.manual_seed(0)
     blk0 = M.multimae_utils.Block(128, 4, qkv_bias=True, norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6)).cuda()
@@ -93,15 +93,59 @@ def test_dropout_settings_are_the_identity_in_eval_mode_and_drop_in_training_mod
     blk.load_state_dict(blk0.state_dict(), strict=True)
     x = torch.randn(4, 40, 128, device="cuda")
     assert torch.equal(blk.eval()(x), blk0.eval()(x))
-    with pytest.raises(NotImplementedError):
-        blk.train()(x)
-    blk.attn.attn_drop = 0.0
     y = blk.train()(x.requires_grad_())
     y.sum().backward()
     assert torch.isfinite(y).all() and torch.isfinite(x.grad).all() and blk.mlp.fc1.weight.grad is not None
     mlp = M.multimae_utils.Mlp(128, 512, drop=0.25).cuda().train()
     frac = (mlp(torch.randn(64, 40, 128, device="cuda")) == 0).float().mean().item()
     assert 0.2 < frac < 0.3, frac
+
+
+@pytest.mark.parametrize("cross", [False, True])
+def test_dropout_on_the_attention_probabilities_in_training_mode(cross):
+    """attn_drop > 0 in training mode (reference: multimae/multimae_utils.py:200-204, :240-244): one dropout call on the
+    [B,H,Nq,Nk] probabilities between softmax and the value product.  Checked against the same arithmetic written out in fp32
+    with the same seed (the same call on a tensor of the same shape draws the same mask): output and input gradients within the
+    bf16 tolerance of the projections, about attn_drop of the probabilities dropped, eval mode equal to the module without
+    dropout."""
+    import torch.nn.functional as F
+    import multimae_amd as M
+    torch.manual_seed(1)
+    B, N, Mctx, D, H, p = 3, 40, 23, 128, 4, 0.2
+    mod = (M.multimae_utils.CrossAttention if cross else M.multimae_utils.Attention)(D, num_heads=H, qkv_bias=True, attn_drop=p).cuda()
+    x = torch.randn(B, N, D, device="cuda", requires_grad=True)
+    ctx = torch.randn(B, Mctx, D, device="cuda", requires_grad=True) if cross else None
+    args = (x, ctx) if cross else (x,)
+
+    def written_out(x, ctx):
+        d = D // H
+        if cross:
+            q = F.linear(x, mod.q.weight, mod.q.bias).reshape(B, N, H, d).permute(0, 2, 1, 3)
+            k, v = F.linear(ctx, mod.kv.weight, mod.kv.bias).reshape(B, Mctx, 2, H, d).permute(2, 0, 3, 1, 4).unbind(0)
+        else:
+            q, k, v = F.linear(x, mod.qkv.weight, mod.qkv.bias).reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4).unbind(0)
+        attn = F.dropout(((q @ k.transpose(-2, -1)) * d ** -0.5).softmax(-1), p, True)
+        dropped = (attn == 0).float().mean().item()
+        return F.linear((attn @ v).transpose(1, 2).reshape(B, N, D), mod.proj.weight, mod.proj.bias), dropped
+
+    g = torch.randn(B, N, D, device="cuda")
+    torch.manual_seed(7)
+    y = mod.train()(*args)
+    y.backward(g)
+    got = [y.detach().clone()] + [t.grad.clone() for t in args] + [mod.proj.weight.grad.clone()]
+    for t in args:
+        t.grad = None
+    mod.proj.weight.grad = None
+    torch.manual_seed(7)
+    yr, dropped = written_out(*((x, ctx) if cross else (x, None)))
+    yr.backward(g)
+    want = [yr.detach()] + [t.grad for t in args] + [mod.proj.weight.grad]
+    assert 0.15 < dropped < 0.25, dropped
+    for a, b in zip(got, want):
+        assert rel_err(a, b) < BF16_TOL, rel_err(a, b)
+    plain = (M.multimae_utils.CrossAttention if cross else M.multimae_utils.Attention)(D, num_heads=H, qkv_bias=True).cuda()
+    plain.load_state_dict(mod.state_dict())
+    assert torch.equal(mod.eval()(*args), plain.eval()(*args))
 
 
 def test_learnable_output_position_table_is_refused_as_in_the_reference():
