@@ -795,3 +795,19 @@ def test_truncated_depth_standardisation(ops):
     x = d.cuda().clone()
     ops.standardize_depth(x, out=x)          # in place
     assert torch.equal(x, got)
+
+
+@pytest.mark.parametrize("h,w", [(64, 64), (37, 100), (176, 176), (256, 256), (260, 256), (384, 384)])
+def test_truncated_depth_standardisation_sizes(ops, h, w):
+    """Every instantiation of the register form (16 / 32 / 49 / 64 values per thread: up to 65,536 pixels, the last size exactly),
+    a map that does not fill its threads evenly, and the memory form beyond (384^2 is the ViT-L configuration's size): against the
+    oracle, with ties across both cut ranks in one sample, and repeatable bitwise."""
+    from oracle import multimae_oracle as O
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    d = torch.rand(3, 1, h, w, generator=g) * 5.0 - 1.0
+    d[1] = torch.round(d[1] * 2) / 2
+    ref = O.standardize_depth(d)
+    got = ops.standardize_depth(d.cuda())
+    for b in range(3):
+        assert rel_err(got[b].cpu(), ref[b]) < FP32_TOL, b
+    assert torch.equal(got, ops.standardize_depth(d.cuda()))
