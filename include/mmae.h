@@ -294,6 +294,16 @@ int mmae_adamw_flat(float* p, const float* g, float* m, float* v, long n, long n
                     float beta2, float eps, float weight_decay, int step, float grad_scale, void* w_bf16,
                     const float* grad_sumsq, float max_norm, float skip_norm, int* step_dev, mmae_stream_t stream);
 /* sum of squares of f32 [n] into out[0] (f32); partials in workspace (>= 4096 bytes) */
+/* mmae_adamw_flat with two by-products of its read of the gradients, for the update that runs range by range beside backward
+ * (no clipping / skipping): clear_grad != 0 writes zeros over g behind the read (the optimizer.zero_grad() of the next
+ * iteration, run_pretraining_multimae.py:507), and sumsq_part (or NULL) receives mmae_adamw_flat_parts(n) partial sums of g^2 over
+ * the range (raw gradients, before grad_scale): the squared norm of utils/native_scaler.py:63-83 is mmae_sum_partials over
+ * the parts of all ranges, added in a fixed order. */
+int mmae_adamw_flat_parts(long n);
+int mmae_adamw_flat_ex(float* p, float* g, float* m, float* v, long n, long n_decay, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, int step, float grad_scale, void* w_bf16, const float* grad_sumsq, float max_norm,
+                       float skip_norm, int* step_dev, int clear_grad, float* sumsq_part, mmae_stream_t stream);
+int mmae_sum_partials(const float* part, int nparts, float* out, mmae_stream_t stream);
 int mmae_sumsq(const float* x, long n, float* out, void* workspace, size_t workspace_bytes, mmae_stream_t stream);
 /* dst(bf16)[rows, cols] = src(f32)[rows, cols]; dst_t(bf16)[cols, rows] = transpose (either may be NULL) */
 int mmae_cast_transpose(const float* src, int rows, int cols, void* dst_bf16, void* dst_t_bf16, mmae_stream_t stream);

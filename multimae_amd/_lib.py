@@ -65,6 +65,9 @@ SIGNATURES = {
     "mmae_masked_loss_static": (_i, [_i, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "mmae_standardize_depth": (_i, [_p, _p, _i, _l, C.c_double, C.c_double, _f, _p]),
     "mmae_adamw_flat": (_i, [_p, _p, _p, _p, _l, _l, _f, _f, _f, _f, _f, _i, _f, _p, _p, _f, _f, _p, _p]),
+    "mmae_adamw_flat_parts": (_i, [_l]),
+    "mmae_adamw_flat_ex": (_i, [_p, _p, _p, _p, _l, _l, _f, _f, _f, _f, _f, _i, _f, _p, _p, _f, _f, _p, _i, _p, _p]),
+    "mmae_sum_partials": (_i, [_p, _i, _p, _p]),
     "mmae_sumsq": (_i, [_p, _l, _p, _p, _z, _p]),
     "mmae_cast_transpose": (_i, [_p, _i, _i, _p, _p, _p]),
     "mmae_transpose_multi": (_i, [_p, _p, _p, _i, _i, _p]),

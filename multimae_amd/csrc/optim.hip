@@ -13,6 +13,8 @@ struct AdamArgs {
     const float* sumsq; float max_norm, skip_norm;
     int* step_dev;
     bf16* wb;
+    float* gclear;      // not null: the gradient range, cleared behind the read (the next step accumulates into it again)
+    float* sumsq_part;  // not null: [gridDim.x] partial sums of g^2 over the range (raw gradients, before gscale)
 };
 
 __device__ __forceinline__ bool adam_plan(const AdamArgs& a, float& gs, int& step) {
@@ -35,9 +37,14 @@ __global__ void adamw_flat_kernel(AdamArgs a) {
     const float bc2_sqrt = sqrtf(1.0f - powf(a.b2, (float)t));
     const float step = a.lr / bc1, lr = a.lr, wd = a.wd, b1 = a.b1, b2 = a.b2, eps = a.eps;
     float* p = a.p; float* m = a.m; float* v = a.v; const float* g = a.g; bf16* wb = a.wb;
+    __shared__ float red[16];
+    float ss = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n4; i += (long)gridDim.x * blockDim.x) {
         f32x4 pp = ((f32x4*)p)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
-        const f32x4 gg = ((const f32x4*)g)[i] * gscale;
+        const f32x4 graw = ((const f32x4*)g)[i];
+        if (a.sumsq_part) ss += graw[0] * graw[0] + graw[1] * graw[1] + graw[2] * graw[2] + graw[3] * graw[3];
+        if (a.gclear) ((f32x4*)a.gclear)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 gg = graw * gscale;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float x = pp[e];
@@ -53,6 +60,10 @@ __global__ void adamw_flat_kernel(AdamArgs a) {
             ((bf16x4*)wb)[i] = o;
         }
     }
+    if (a.sumsq_part) {  // fixed order: a thread's elements in index order, then the block's threads (block_sum)
+        ss = block_sum(ss, red);
+        if (threadIdx.x == 0) a.sumsq_part[blockIdx.x] = ss;
+    }
 }
 // runs after the update kernel on the same stream: advance the device step count unless the update was skipped
 __global__ void adamw_advance_kernel(AdamArgs a) {
@@ -60,24 +71,36 @@ __global__ void adamw_advance_kernel(AdamArgs a) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && adam_plan(a, gs, t)) a.step_dev[0] = t;
 }
 
-extern "C" int mmae_adamw_flat(float* p, const float* g, float* m, float* v, long n, long n_decay, float lr, float beta1,
-                               float beta2, float eps, float weight_decay, int step, float grad_scale, void* w_bf16,
-                               const float* grad_sumsq, float max_norm, float skip_norm, int* step_dev, hipStream_t stream) {
+static int adamw_blocks(long n) { long b = (n / 4 + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+extern "C" int mmae_adamw_flat_parts(long n) { return adamw_blocks(n); }
+
+extern "C" int mmae_adamw_flat_ex(float* p, float* g, float* m, float* v, long n, long n_decay, float lr, float beta1, float beta2,
+                                  float eps, float weight_decay, int step, float grad_scale, void* w_bf16, const float* grad_sumsq,
+                                  float max_norm, float skip_norm, int* step_dev, int clear_grad, float* sumsq_part,
+                                  hipStream_t stream) {
     MMAE_REQUIRE(p && g && m && v, MMAE_EINVAL, "adamw_flat: null pointer");
     MMAE_REQUIRE(n >= 0 && n % 4 == 0 && n_decay >= 0 && n_decay <= n, MMAE_ESHAPE, "adamw_flat: n=%ld must be a multiple of 4, n_decay=%ld within it", n, n_decay);
     MMAE_REQUIRE(step_dev || step >= 1, MMAE_EINVAL, "adamw_flat: step counts from 1");
     MMAE_REQUIRE(grad_sumsq || (max_norm <= 0.f && skip_norm <= 0.f), MMAE_EINVAL, "adamw_flat: clipping / skipping needs the gradient sum of squares");
+    // a skipped update returns before the loop: its gradients would be neither summed nor cleared
+    MMAE_REQUIRE(!(clear_grad || sumsq_part) || !(skip_norm > 0.f), MMAE_EINVAL, "adamw_flat: clear_grad / sumsq_part cannot be combined with skipping");
     if (n == 0) return MMAE_OK;
     AdamArgs a = {p, g, m, v, n / 4, n_decay, lr, beta1, beta2, eps, weight_decay, grad_scale, step, grad_sumsq, max_norm, skip_norm,
-                  step_dev, (bf16*)w_bf16};
-    int blocks = (int)((a.n4 + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(adamw_flat_kernel, dim3(blocks), dim3(256), 0, stream, a);
+                  step_dev, (bf16*)w_bf16, clear_grad ? g : nullptr, sumsq_part};
+    hipLaunchKernelGGL(adamw_flat_kernel, dim3(adamw_blocks(n)), dim3(256), 0, stream, a);
     MMAE_CHECK_LAUNCH("adamw_flat");
     if (step_dev) {
         hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(64), 0, stream, a);
         MMAE_CHECK_LAUNCH("adamw_advance");
     }
     return MMAE_OK;
+}
+
+extern "C" int mmae_adamw_flat(float* p, const float* g, float* m, float* v, long n, long n_decay, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int step, float grad_scale, void* w_bf16,
+                               const float* grad_sumsq, float max_norm, float skip_norm, int* step_dev, hipStream_t stream) {
+    return mmae_adamw_flat_ex(p, (float*)g, m, v, n, n_decay, lr, beta1, beta2, eps, weight_decay, step, grad_scale, w_bf16, grad_sumsq,
+                              max_norm, skip_norm, step_dev, 0, nullptr, stream);
 }
 
 #define SUMSQ_BLOCKS 1024
@@ -99,6 +122,13 @@ __global__ void sumsq_final_kernel(const float* __restrict__ part, int nparts, f
     for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += part[i];
     s = block_sum(s, red);
     if (threadIdx.x == 0) out[0] = s;
+}
+// out = sum of part[0 .. nparts) in a fixed order (the partial sums mmae_adamw_flat_ex leaves, over all of a step's ranges)
+extern "C" int mmae_sum_partials(const float* part, int nparts, float* out, hipStream_t stream) {
+    MMAE_REQUIRE(part && out && nparts > 0, MMAE_EINVAL, "sum_partials: bad argument");
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, part, nparts, out);
+    MMAE_CHECK_LAUNCH("sum_partials");
+    return MMAE_OK;
 }
 extern "C" int mmae_sumsq(const float* x, long n, float* out, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     MMAE_REQUIRE(x && out && workspace, MMAE_EINVAL, "sumsq: null pointer");

@@ -613,18 +613,39 @@ def standardize_depth(depth: torch.Tensor, lo_frac: float = 0.1, hi_frac: float 
 
 # --------------------------------------------------------------------------------------------- optimiser
 def adamw_flat(p, g, m, v, n_decay, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, w_bf16=None, grad_sumsq=None,
-               max_norm=0.0, skip_norm=0.0, step_dev=None):
+               max_norm=0.0, skip_norm=0.0, step_dev=None, clear_grad=False, sumsq_part=None):
+    """clear_grad: g is zeroed behind the read; sumsq_part: f32 [>= adamw_parts(p.numel())] receives partial sums of g^2
+    (sum_partials over the parts of every range of a step gives the squared gradient norm)."""
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _req(t, F32, f"adamw {n}")
+    if sumsq_part is not None:
+        _req(sumsq_part, F32, "adamw sumsq_part")
+        if sumsq_part.numel() < adamw_parts(p.numel()):
+            raise ValueError("adamw_flat: sumsq_part too small")
     if grad_sumsq is not None:
         _req(grad_sumsq, F32, "adamw grad_sumsq")
     if step_dev is not None:
         _req(step_dev, torch.int32, "adamw step_dev")
     # p, g, m, v in; p, m, v (and the bf16 weights) out
-    with _Timed("adamw", 0.0, "adamw_flat_kernel", nbytes=p.numel() * (28 + (2 if w_bf16 is not None else 0))):
-        _lib.check(_L().mmae_adamw_flat(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(n_decay), lr, beta1, beta2, eps,
-                                        weight_decay, int(step), float(grad_scale), _ptr(w_bf16), _ptr(grad_sumsq), float(max_norm or 0.0),
-                                        float(skip_norm or 0.0), _ptr(step_dev), _stream()), "adamw_flat")
+    with _Timed("adamw", 0.0, "adamw_flat_kernel", nbytes=p.numel() * (28 + (2 if w_bf16 is not None else 0) + (4 if clear_grad else 0))):
+        _lib.check(_L().mmae_adamw_flat_ex(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(n_decay), lr, beta1, beta2, eps,
+                                           weight_decay, int(step), float(grad_scale), _ptr(w_bf16), _ptr(grad_sumsq), float(max_norm or 0.0),
+                                           float(skip_norm or 0.0), _ptr(step_dev), int(bool(clear_grad)), _ptr(sumsq_part), _stream()),
+                   "adamw_flat")
+
+
+def adamw_parts(n: int) -> int:
+    """Partial sums one adamw_flat call over n elements writes into sumsq_part."""
+    return int(_L().mmae_adamw_flat_parts(int(n)))
+
+
+def sum_partials(part: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """Sum of an f32 vector in a fixed order (device scalar)."""
+    _req(part, F32, "sum_partials part")
+    if out is None:
+        out = torch.empty((), dtype=F32, device=part.device)
+    _lib.check(_L().mmae_sum_partials(_ptr(part), part.numel(), _ptr(out), _stream()), "sum_partials")
+    return out
 
 
 def sumsq(x: torch.Tensor, out: Optional[torch.Tensor] = None):

@@ -559,17 +559,20 @@ class FlatAdamW:
             raise ValueError("FlatAdamW applies one learning rate to both parameter groups")
         self.step_count += 1
 
-    def step_range(self, start: int, end: int, grad_scale: float = 1.0, transpose_table=None):
+    def step_range(self, start: int, end: int, grad_scale: float = 1.0, transpose_table=None, clear_grad=False, sumsq_part=None):
         """The update of begin_step()'s step for flat elements [start, end) (a range that does not straddle the decayed /
         not decayed boundary), on the current stream; `transpose_table` = (int32 table, tiles) of the 2-D weights inside
-        the range refreshes their transposed bf16 copies.  No clipping / skipping: those need the whole gradient first."""
+        the range refreshes their transposed bf16 copies.  No clipping / skipping: those need the whole gradient first.
+        clear_grad: the range's gradients are zeroed behind the read (the next iteration's zero_grad); sumsq_part: receives
+        ops.adamw_parts(end - start) partial sums of the range's squared gradients (see ops.adamw_flat)."""
         nd = self.flat.n_decay
         if start < nd < end:
             raise ValueError("step_range: the range straddles the weight-decay boundary")
         f = self.flat
         ops.adamw_flat(f.params[start:end], f.grads[start:end], self.exp_avg[start:end], self.exp_avg_sq[start:end],
                        end - start if start < nd else 0, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                       self.step_count, grad_scale, w_bf16=None if f.w_bf16 is None else f.w_bf16[start:end])
+                       self.step_count, grad_scale, w_bf16=None if f.w_bf16 is None else f.w_bf16[start:end],
+                       clear_grad=clear_grad, sumsq_part=sumsq_part)
         if transpose_table is not None and transpose_table[0] is not None:
             ops.transpose_multi(f.w_bf16, f.wt_bf16, transpose_table[0], transpose_table[1])
 
@@ -615,11 +618,14 @@ class PretrainStep:
     def __init__(self, model, losses, num_encoded_tokens=98, alphas=1.0, lr=1e-4, weight_decay=0.05, betas=(0.9, 0.95),
                  bucket_mb=64.0, clip_grad=None, skip_grad=None, lr_schedule_values=None, wd_schedule_values=None,
                  start_step=0, sample_tasks_uniformly=False, fp32_output_adapters=(), standardize_depth=False,
-                 eager_optimizer=None, max_steps_in_flight=None, loss_on_unmasked=False):
+                 eager_optimizer=None, max_steps_in_flight=None, loss_on_unmasked=False, keep_grads=False):
         """clip_grad / skip_grad: max_norm / max_skip_norm of the reference's train_one_epoch
         (run_pretraining_multimae.py:512-519).  lr_schedule_values / wd_schedule_values: per-iteration arrays
         (cosine_scheduler) applied before each step as at :424-436; iteration = start_step + calls so far.
-        loss_on_unmasked: the losses average over every token instead of the masked ones (:491-496)."""
+        loss_on_unmasked: the losses average over every token instead of the masked ones (:491-496).
+        keep_grads: leave the step's gradients in `p.grad` after the call (for inspection).  By default the bucket-wise
+        update clears each gradient range behind its read, which is the next iteration's `optimizer.zero_grad()` (:507)
+        done early; with clipping / skipping (update at the end of the step) the gradients stay either way."""
         self.model, self.losses = model, losses
         self.k, self.alphas = num_encoded_tokens, alphas
         self.clip_grad, self.skip_grad = clip_grad, skip_grad
@@ -649,6 +655,15 @@ class PretrainStep:
             self._tr_tables = [self.flat.transpose_table_for(s, e) for s, e, _ in self.buckets.buckets]
             self.buckets.install_hooks()
             self.buckets.after_bucket = self._update_bucket
+            # The bucket-wise update reads every gradient exactly once, after it is final: the same read leaves the partial
+            # sums of the squared gradient norm and clears the gradients for the next step, so neither a norm pass nor a
+            # fill pass over the 0.4-GB buffer runs between two steps.
+            counts = [ops.adamw_parts(e - s) for s, e, _ in self.buckets.buckets]
+            self._part_ranges = [(sum(counts[:b]), sum(counts[:b + 1])) for b in range(len(counts))]
+            self._norm_parts = torch.zeros(sum(counts), dtype=torch.float32, device=self.flat.params.device)
+        self.keep_grads = bool(keep_grads)
+        self._grads_clean = False  # True after a step in which every bucket was updated (and thereby cleared)
+        self._updates = 0
         self._armed = False
         # The host enqueues a step several times faster than the device runs it and never has to wait for it, so without a
         # bound it runs many steps ahead.  Memory then grows with the distance: buffers that were used on a second stream are
@@ -663,9 +678,13 @@ class PretrainStep:
 
     def _update_bucket(self, b, start, end, stream):
         if not self._armed:  # a backward pass through the model outside this step (tests, probes): gradients only
+            self._grads_clean = False
             return
+        lo, hi = self._part_ranges[b]
         with torch.cuda.stream(stream):
-            self.opt.step_range(start, end, grad_scale=1.0 / self.world, transpose_table=self._tr_tables[b])
+            self.opt.step_range(start, end, grad_scale=1.0 / self.world, transpose_table=self._tr_tables[b],
+                                clear_grad=not self.keep_grads, sumsq_part=self._norm_parts[lo:hi])
+        self._updates += 1
 
     def __call__(self, batch, mask_randomness=None):
         if self.lr_values is not None:
@@ -678,7 +697,9 @@ class PretrainStep:
                 ev = self._step_events.pop(0)
                 if not ev.query():
                     ev.synchronize()
-        self.flat.zero_grad()
+        if not (self.eager and self._grads_clean):
+            self.flat.zero_grad()
+        self._grads_clean, self._updates = False, 0
         if self.eager:
             self.opt.begin_step()
         if self.standardize_depth and "depth" in batch:
@@ -699,7 +720,12 @@ class PretrainStep:
         finally:
             self._armed = False
         Fn.join_side_stream()
-        gn2 = self.opt.grad_norm_sq()  # of the summed (not yet averaged) gradients: norm = sqrt(gn2) / world
+        # squared norm of the summed (not yet averaged) gradients: norm = sqrt(gn2) / world
+        if self.eager and self._updates == len(self.buckets.buckets):
+            gn2 = ops.sum_partials(self._norm_parts)  # left by the bucket updates, which also cleared the gradients
+            self._grads_clean = not self.keep_grads
+        else:
+            gn2 = self.opt.grad_norm_sq()
         if self.eager:
             self.opt.end_step()  # every bucket was updated as it completed
         else:

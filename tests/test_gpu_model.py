@@ -168,7 +168,7 @@ def test_flat_storage_step_matches_autograd_path():
     opt.step()
 
     model = _build(cfg); model.load_state_dict(sd); model.cuda()
-    step = PretrainStep(model, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05)
+    step = PretrainStep(model, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05, keep_grads=True)
     loss, task_losses, gn2 = step(x, mask_randomness=rnd)
     grads = {n: p.grad for n, p in model.named_parameters() if p.requires_grad}
     assert all(g.data_ptr() >= step.flat.grads.data_ptr() for g in grads.values())
@@ -645,7 +645,9 @@ def test_decoder_streams_do_not_change_the_step():
 def test_bucketwise_optimizer_equals_the_update_at_the_end_of_the_step():
     """Without clipping the optimizer runs bucket by bucket beside backward (PretrainStep.eager); the element-wise AdamW
     arithmetic is the same, so three steps must end on bitwise the parameters, moments and bf16 weight copies of the
-    update applied once at the end; with clipping the step falls back to the end-of-step update."""
+    update applied once at the end; with clipping the step falls back to the end-of-step update.  The bucket-wise update
+    also leaves the squared gradient norm (partial sums per bucket, so equal to the separate pass up to the order of the
+    additions) and clears the gradients behind its read unless keep_grads is set."""
     from oracle import multimae_oracle as O
     from tests.golden import common as G
     from multimae_amd import functional as Fn
@@ -653,22 +655,30 @@ def test_bucketwise_optimizer_equals_the_update_at_the_end_of_the_step():
     cfg = O.small_cfg()
     x = {d: t.cuda() for d, t in G.seeded_inputs(cfg, B=4, seed=3).items()}
     rnd = O.draw_mask_randomness(4, [16, 16], 1.0, torch.Generator().manual_seed(2))
-    res = []
-    for eager in (True, False):
+    res, norms, grads = [], [], []
+    for eager, keep in ((True, False), (True, True), (False, False)):
         model = _build(cfg)
         model.load_state_dict(G.perturbed_state(cfg, seed=7))
         model.cuda()
-        step = PretrainStep(model, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05, bucket_mb=0.25, eager_optimizer=eager)
+        step = PretrainStep(model, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05, bucket_mb=0.25, eager_optimizer=eager,
+                            keep_grads=keep)
         assert step.eager == eager and len(step.buckets.buckets) > 3
         for _ in range(3):
             loss, _, gn2 = step(x, mask_randomness=rnd)
         torch.cuda.synchronize()
         wt = torch.cat([Fn.bf16_weights(q)[1].flatten() for q in model.parameters() if q.requires_grad and q.ndim == 2])
         res.append((step.flat.params.clone(), step.opt.exp_avg.clone(), step.opt.exp_avg_sq.clone(), step.flat.w_bf16.clone(),
-                    wt, loss.clone(), gn2.clone()))
+                    wt, loss.clone()))
+        norms.append(gn2.item())
+        grads.append(step.flat.grads.clone())
         assert step.opt.step_count == 3
-    for a, b in zip(*res):
-        assert torch.equal(a, b)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
+    assert norms[0] == norms[1] and abs(norms[0] - norms[2]) <= 1e-6 * norms[2] and norms[2] > 0
+    assert not grads[0].any()                      # cleared by the bucket updates: the next step starts without a fill pass
+    assert torch.equal(grads[1], grads[2]) and grads[1].abs().sum() > 0
+    assert abs(grads[1].double().pow(2).sum().item() - norms[1]) <= 1e-5 * norms[1]
     clipped = PretrainStep(_build(cfg).cuda(), _losses(cfg), num_encoded_tokens=8, clip_grad=1.0)
     assert not clipped.eager
 
@@ -919,7 +929,7 @@ def test_pretrain_step_loss_on_unmasked_vs_oracle():
     model = _build(cfg)
     model.load_state_dict(sd, strict=True)
     model.cuda()
-    step = PretrainStep(model, _losses(cfg), num_encoded_tokens=k, lr=0.0, weight_decay=0.0, loss_on_unmasked=True)
+    step = PretrainStep(model, _losses(cfg), num_encoded_tokens=k, lr=0.0, weight_decay=0.0, loss_on_unmasked=True, keep_grads=True)
     loss, task_losses, _ = step({d: t.cuda() for d, t in x.items()}, mask_randomness=rnd)
     errs = {f"loss_{t}": abs(task_losses[t].item() - float(o_losses[t].detach())) / abs(float(o_losses[t].detach())) for t in o_losses}
     errs.update({"grad_" + n: rel_err(p.grad.cpu(), o_grads[n]) for n, p in model.named_parameters() if p.requires_grad})
