@@ -662,6 +662,7 @@ class PretrainStep:
             self._part_ranges = [(sum(counts[:b]), sum(counts[:b + 1])) for b in range(len(counts))]
             self._norm_parts = torch.zeros(sum(counts), dtype=torch.float32, device=self.flat.params.device)
         self.keep_grads = bool(keep_grads)
+        self._fused_norm = os.environ.get("MMAE_FUSED_NORM", "1") != "0"  # tuning: 0 = separate norm and fill passes
         self._grads_clean = False  # True after a step in which every bucket was updated (and thereby cleared)
         self._updates = 0
         self._armed = False
@@ -683,7 +684,8 @@ class PretrainStep:
         lo, hi = self._part_ranges[b]
         with torch.cuda.stream(stream):
             self.opt.step_range(start, end, grad_scale=1.0 / self.world, transpose_table=self._tr_tables[b],
-                                clear_grad=not self.keep_grads, sumsq_part=self._norm_parts[lo:hi])
+                                clear_grad=self._fused_norm and not self.keep_grads,
+                                sumsq_part=self._norm_parts[lo:hi] if self._fused_norm else None)
         self._updates += 1
 
     def __call__(self, batch, mask_randomness=None):
@@ -721,7 +723,7 @@ class PretrainStep:
             self._armed = False
         Fn.join_side_stream()
         # squared norm of the summed (not yet averaged) gradients: norm = sqrt(gn2) / world
-        if self.eager and self._updates == len(self.buckets.buckets):
+        if self.eager and self._fused_norm and self._updates == len(self.buckets.buckets):
             gn2 = ops.sum_partials(self._norm_parts)  # left by the bucket updates, which also cleared the gradients
             self._grads_clean = not self.keep_grads
         else:
