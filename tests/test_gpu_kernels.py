@@ -549,6 +549,29 @@ def test_adamw_sumsq_cast(ops):
     assert torch.equal(ops.cast_bf16(w), w.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("n", [4, 1_000_004, 5_000_000])
+def test_adamw_by_products_clear_the_gradients_and_leave_the_norm(ops, n):
+    """mmae_adamw_flat_ex: the same update as mmae_adamw_flat bitwise, the gradients zeroed behind the read, and partial sums
+    whose fixed-order total is the squared norm of the raw gradients (before grad_scale); sizes below one block, with a ragged
+    last block, and beyond the 4,096-block grid."""
+    g0 = torch.Generator().manual_seed(n)
+    p = torch.randn(n, generator=g0).cuda(); grad = torch.randn(n, generator=g0).cuda()
+    state = [torch.zeros_like(p) for _ in range(2)] + [torch.zeros_like(p) for _ in range(2)]
+    p2, g2 = p.clone(), grad.clone()
+    parts = torch.full((ops.adamw_parts(n) + 3,), 7.0, device="cuda")
+    ops.adamw_flat(p, grad, state[0], state[1], n // 2 // 4 * 4, 1e-3, 0.9, 0.95, 1e-8, 0.05, 1, grad_scale=0.25)
+    ops.adamw_flat(p2, g2, state[2], state[3], n // 2 // 4 * 4, 1e-3, 0.9, 0.95, 1e-8, 0.05, 1, grad_scale=0.25, clear_grad=True,
+                   sumsq_part=parts)
+    assert torch.equal(p, p2) and torch.equal(state[0], state[2]) and torch.equal(state[1], state[3])
+    assert not g2.any() and torch.equal(parts[-3:], torch.full((3,), 7.0, device="cuda"))  # writes exactly adamw_parts(n) sums
+    want = (grad.double() ** 2).sum().item()
+    got = ops.sum_partials(parts[:-3]).item()
+    assert abs(got - want) <= 1e-5 * want
+    assert ops.sum_partials(parts[:-3]).item() == got
+    with pytest.raises(ValueError):
+        ops.adamw_flat(p2, g2, state[2], state[3], 0, 1e-3, 0.9, 0.95, 1e-8, 0.05, 2, sumsq_part=parts[:max(ops.adamw_parts(n) - 1, 0)])
+
+
 # ---------------------------------------------------------------------------------------------- losses
 def _loss_fns():
     from oracle import multimae_oracle as O
