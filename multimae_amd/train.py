@@ -190,9 +190,12 @@ class FlatParams:
                 p._mmae_bf16_views = (self.w_bf16[o:o + n * k].view(n, k), self.wt_bf16[o:o + n * k].view(k, n),
                                       p._version, self.sync_bf16)
 
-    def zero_grad(self):
-        Fn.join_side_stream(self.grads.device)
-        self.grads.zero_()
+    def zero_grad(self, fill: bool = True):
+        """fill=False: the buffer is known to be zero already (the bucket-wise update cleared it); only the `.grad` views are
+        re-attached."""
+        if fill:
+            Fn.join_side_stream(self.grads.device)
+            self.grads.zero_()
         for (_, p), o in zip(self.named, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * o:
                 p.grad = self.grads[o:o + p.numel()].view(p.shape)  # re-attach after zero_grad(set_to_none=True)
@@ -699,8 +702,7 @@ class PretrainStep:
                 ev = self._step_events.pop(0)
                 if not ev.query():
                     ev.synchronize()
-        if not (self.eager and self._grads_clean):
-            self.flat.zero_grad()
+        self.flat.zero_grad(fill=not (self.eager and self._grads_clean))
         self._grads_clean, self._updates = False, 0
         if self.eager:
             self.opt.begin_step()

@@ -681,6 +681,22 @@ def test_bucketwise_optimizer_equals_the_update_at_the_end_of_the_step():
     assert abs(grads[1].double().pow(2).sum().item() - norms[1]) <= 1e-5 * norms[1]
     clipped = PretrainStep(_build(cfg).cuda(), _losses(cfg), num_encoded_tokens=8, clip_grad=1.0)
     assert not clipped.eager
+    # a caller that drops the gradients between steps (model.zero_grad(set_to_none=True)) or runs a backward pass of its own
+    # does not disturb the step that skips its fill pass
+    model = _build(cfg)
+    model.load_state_dict(G.perturbed_state(cfg, seed=7))
+    model.cuda()
+    step = PretrainStep(model, _losses(cfg), num_encoded_tokens=8, lr=1e-3, weight_decay=0.05, bucket_mb=0.25)
+    step(x, mask_randomness=rnd)
+    model.zero_grad(set_to_none=True)
+    step(x, mask_randomness=rnd)
+    preds, masks = model(x, num_encoded_tokens=8, mask_randomness=rnd)
+    sum(fn(preds[t], x[tgt], mask=masks[tgt]) for t, (fn, tgt) in _losses(cfg).items()).backward()  # leaves gradients behind
+    Fn.join_side_stream()
+    assert step.flat.grads.any()
+    step(x, mask_randomness=rnd)
+    torch.cuda.synchronize()
+    assert torch.equal(step.flat.params, res[0][0]) and not step.flat.grads.any()
 
 
 def test_full_batch_step_is_the_mean_of_its_chunks():
