@@ -361,6 +361,12 @@ int mmae_comm_destroy(void* handle);
 
 /* One idle workgroup for `us` microseconds on `stream` (no reference counterpart).  The host side times pairs of these on
  * two streams to learn whether the streams share a hardware queue (a process has 4; streams on one queue do not overlap). */
+/* CUs that the one-workgroup-per-CU GEMM kernels plan their tiles, splits and grids for (no reference counterpart: the
+ * reference leaves CU sharing between DDP's NCCL kernels and its matrix products to the libraries).  n = 0: all CUs (default);
+ * 32 <= n < CUs: leave the others free, e.g. for the channels of a collective that runs beside the products (a workgroup
+ * of these kernels cannot share a CU with another kernel's resident workgroup and would otherwise start a tile time
+ * late).  Process-wide; returns the count in effect.  Env MMAE_CU_BUDGET sets the initial value. */
+int mmae_set_cu_budget(int n);
 int mmae_spin_us(int us, mmae_stream_t stream);
 
 #ifdef __cplusplus

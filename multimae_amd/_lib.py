@@ -87,6 +87,7 @@ SIGNATURES = {
     "mmae_comm_info": (_i, [_p, C.POINTER(_i), C.POINTER(_i)]),
     "mmae_comm_destroy": (_i, [_p]),
     "mmae_spin_us": (_i, [_i, _p]),
+    "mmae_set_cu_budget": (_i, [_i]),
 }
 
 

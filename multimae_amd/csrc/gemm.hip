@@ -1005,6 +1005,13 @@ static PpPlan pp_plan(int M, int N, int K) {
     }
     return pl;
 }
+// CUs the one-workgroup-per-CU kernels plan for.  A workgroup of those kernels needs a whole CU (150 KB of LDS, every vector
+// register of its SIMDs), so it cannot share one with a resident workgroup of another kernel: while a collective's kernel
+// holds R CUs, a grid planned for all CUs starts R workgroups late, and with one round of tiles per launch those finish a
+// whole tile time after the rest.  With a budget of (CUs - R) every workgroup of these kernels finds a free CU at once and
+// the collective keeps its own (set by the data-parallel host code while a communicator with more than one rank exists;
+// env MMAE_CU_BUDGET for experiments).  0 = all CUs.
+static int g_cu_budget = -1;
 static int num_cus() {
     if (g_num_cus == 0) {
         int dev = 0, n = 0;
@@ -1013,7 +1020,15 @@ static int num_cus() {
         else
             g_num_cus = 256;
     }
-    return g_num_cus;
+    if (g_cu_budget < 0) {
+        const char* e = getenv("MMAE_CU_BUDGET");
+        g_cu_budget = e ? atoi(e) : 0;
+    }
+    return (g_cu_budget >= 32 && g_cu_budget < g_num_cus) ? g_cu_budget : g_num_cus;
+}
+extern "C" int mmae_set_cu_budget(int n) {
+    g_cu_budget = n > 0 ? n : 0;
+    return num_cus();
 }
 
 template <int EPI, int WM, int STAGES>

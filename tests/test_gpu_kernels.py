@@ -165,6 +165,30 @@ def test_gemm_tn(ops, tn_variant, M, N, K):
     assert rel_err(acc, 2 * x.float().sum(0)) < FP32_TOL and rel_err(out2, 3 * ref) < FP32_TOL
 
 
+@pytest.mark.parametrize("budget", [248, 200, 96])
+def test_gemm_with_a_cu_budget(ops, budget):
+    """mmae_set_cu_budget: the one-workgroup-per-CU kernels plan their tiles, tails and splits for fewer CUs (left free for a
+    collective's kernels); same results to rounding (the split of the weight-gradient reduction changes), at the step's shapes
+    with a tail launch (N = 768), without (N = 2304) and for the split-M weight gradient."""
+    L = ops._L()
+    a, w, bias = _randn(25344, 768, seed=61), _randn(768, 768, seed=62, scale=0.05), _randn(768, seed=63, dtype=torch.float32)
+    w2 = _randn(2304, 768, seed=64, scale=0.05)
+    res = torch.randn(25344, 768, device="cuda")
+    dy = _randn(25344, 2304, seed=65)
+    want = (ops.gemm_nt(ops.EPI_BF16, a, w, bias), ops.gemm_nt(ops.EPI_RESID, a, w, bias, aux=res), ops.gemm_nt(ops.EPI_BF16, a, w2, None),
+            ops.gemm_tn(dy, a))
+    try:
+        assert L.mmae_set_cu_budget(budget) == budget
+        got = (ops.gemm_nt(ops.EPI_BF16, a, w, bias), ops.gemm_nt(ops.EPI_RESID, a, w, bias, aux=res), ops.gemm_nt(ops.EPI_BF16, a, w2, None),
+               ops.gemm_tn(dy, a))
+    finally:
+        assert L.mmae_set_cu_budget(0) >= 256
+    for g, r in zip(got[:3], want[:3]):
+        assert torch.equal(g, r)               # a product's accumulation order does not depend on the tile plan
+    assert rel_err(got[3], want[3]) < 1e-6     # the reduction over rows is split differently
+    assert L.mmae_set_cu_budget(8) >= 256 and L.mmae_set_cu_budget(0) >= 256   # below 32: ignored
+
+
 def test_gemm_random_ragged_shapes(ops, nt_variant):
     """A seeded sweep of small and ragged problems (any M, N and K multiples of 8 that fill no tile evenly) through every
     forward-product variant and, once, through both weight-gradient variants: bias and GELU epilogues against fp32 torch."""
