@@ -16,12 +16,14 @@ if os.environ.get("HOG"):
     blocks, busy, period = (int(v) for v in os.environ["HOG"].split(","))
     hog = ctypes.CDLL(os.path.join(HERE, "libhog.so"))
     hog.hog_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
+    hog.hog_fat_launch.argtypes = hog.hog_launch.argtypes
+    launch = hog.hog_fat_launch if os.environ.get("HOG_FAT", "0") == "1" else hog.hog_launch
 
     def loop():
         torch.cuda.set_device(0)
         st = torch.cuda.Stream()
         while not stop.is_set():
-            hog.hog_launch(blocks, 256, busy, st.cuda_stream)
+            launch(blocks, 256, busy, st.cuda_stream)
             st.synchronize()  # at most one hog kernel queued
             time.sleep(max(period - busy, 0) * 1e-6)
 

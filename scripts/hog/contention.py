@@ -13,6 +13,8 @@ from multimae_amd import ops
 
 hog = ctypes.CDLL(os.path.join(HERE, "libhog.so"))
 hog.hog_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
+hog.hog_fat_launch.argtypes = hog.hog_launch.argtypes
+FAT = os.environ.get("HOG_FAT", "0") == "1"  # the hog with a collective kernel's register / LDS footprint
 side = torch.cuda.Stream()
 
 
@@ -25,7 +27,7 @@ def run(fn, H, n=10, hog_us=6000):
     for _ in range(4):
         torch.cuda.synchronize()
         if H:
-            hog.hog_launch(H, 256, hog_us, side.cuda_stream)
+            (hog.hog_fat_launch if FAT else hog.hog_launch)(H, 256, hog_us, side.cuda_stream)
             time.sleep(0.0005)  # let the hog start
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
