@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--comm", choices=("torch", "native"), default=None,
                     help="gradient exchange for N > 1: torch.distributed's RCCL group (default) or the C ABI's own RCCL "
                          "communicator (mmae_comm_*); sets MMAE_COMM")
+    ap.add_argument("--comm-cus", type=int, default=0,
+                    help="CUs left to the gradient exchange: caps RCCL at that many channels (NCCL_MAX_NCHANNELS, unless set) "
+                         "and plans the one-workgroup-per-CU GEMM kernels for the remaining CUs (MMAE_CU_BUDGET); 0 = off")
     ap.add_argument("--no-standardize-depth", action="store_true",
                     help="leave the truncated depth standardisation (the reference's default, on) out of the step")
     return ap.parse_args()
@@ -133,6 +136,9 @@ def main():
     conf = CONFIGS[args.config]
     if args.comm is not None:
         os.environ["MMAE_COMM"] = "native" if args.comm == "native" else "torch"
+    if args.comm_cus > 0:  # before the communicator and the kernel library come up: both read the environment once
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(args.comm_cus))
+        os.environ["MMAE_CU_BUDGET"] = str(-args.comm_cus)  # negative: that many fewer than the device has
     # Only the result line goes to stdout.  Libraries write there on their own when a process group starts (RCCL's version
     # banner, gloo's connection notes): for the duration of the run file descriptor 1 points at stderr, and rank 0 puts it
     # back just for the JSON line.
@@ -303,6 +309,9 @@ def main():
         if roof is not None:
             out["roofline"] = roof
         if world > 1 or comm_info["enabled"]:
+            from multimae_amd import _lib
+            comm_info["planned_cus"] = int(_lib.load().mmae_get_cu_budget())  # CUs the one-workgroup-per-CU kernels plan for
+            comm_info["nccl_max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS")
             out["comm"] = comm_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(conf)

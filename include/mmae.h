@@ -367,6 +367,7 @@ int mmae_comm_destroy(void* handle);
  * of these kernels cannot share a CU with another kernel's resident workgroup and would otherwise start a tile time
  * late).  Process-wide; returns the count in effect.  Env MMAE_CU_BUDGET sets the initial value. */
 int mmae_set_cu_budget(int n);
+int mmae_get_cu_budget(void);  /* the count in effect */
 int mmae_spin_us(int us, mmae_stream_t stream);
 
 #ifdef __cplusplus

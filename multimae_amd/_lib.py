@@ -88,6 +88,7 @@ SIGNATURES = {
     "mmae_comm_destroy": (_i, [_p]),
     "mmae_spin_us": (_i, [_i, _p]),
     "mmae_set_cu_budget": (_i, [_i]),
+    "mmae_get_cu_budget": (_i, []),
 }
 
 

@@ -1020,12 +1020,14 @@ static int num_cus() {
         else
             g_num_cus = 256;
     }
-    if (g_cu_budget < 0) {
+    if (g_cu_budget < 0) {  // first use: the environment (a negative value there counts down from the device's CUs)
         const char* e = getenv("MMAE_CU_BUDGET");
-        g_cu_budget = e ? atoi(e) : 0;
+        const int v = e ? atoi(e) : 0;
+        g_cu_budget = v < 0 ? (g_num_cus + v > 0 ? g_num_cus + v : 0) : v;
     }
     return (g_cu_budget >= 32 && g_cu_budget < g_num_cus) ? g_cu_budget : g_num_cus;
 }
+extern "C" int mmae_get_cu_budget(void) { return num_cus(); }
 extern "C" int mmae_set_cu_budget(int n) {
     g_cu_budget = n > 0 ? n : 0;
     return num_cus();
