@@ -148,8 +148,8 @@ int mmae_attn_fwd(const void* q, long ldq, const void* k, long ldk, const void* 
  * to mmae_attn_max_len(head_dim, 0), MMAE_ESHAPE beyond), 2 = keys streamed through LDS in 64-key tiles with a running softmax
  * (default where the resident images do not fit), 3 = resident in unpadded swizzled images (default where the padded images
  * take more than half of the LDS and these do not).  mmae_attn_fwd_set_one_pass: passes of the resident kernels over the keys,
- * 0 = by layout (default), 1 = one pass with a lazily moved reference point of the exponentials, 2 = two passes (row maximum
- * first).  Per calling thread; for tests and tuning. */
+ * 0 / 1 = one pass with a lazily moved reference point of the exponentials (default), 2 = two passes (row maximum first).
+ * Per calling thread; for tests and tuning. */
 void mmae_attn_fwd_set_variant(int variant);
 void mmae_attn_fwd_set_one_pass(int on);
 /* Longest sequence the LDS-resident kernels take at this head_dim (a multiple of 32; 0 for an unsupported head_dim):

@@ -1028,20 +1028,19 @@ static int launch_with_lds(K kern, const char* name, size_t bytes, int blocks, i
 
 static inline int pad32(int n) { return (n + 31) / 32 * 32; }
 
-// Passes over the keys in the resident forward: 0 = by layout (swizzled images, i.e. long sequences: one pass with a lazily
-// moved reference point, measured 236 -> 207 us at 289 keys / head_dim 64 and 179 -> 173 us at 576 / 32; padded images: one
-// pass at head_dim 32 with 8 or more waves (196 keys: 37.0 -> 34.8 us), else two passes, row maximum first, which is faster
-// at 99 keys / head_dim 64 with 4 waves (33.6 against 36.5 us: the one-pass form needs 152 registers there)),
-// 1 = one pass, 2 = two passes
+// Passes over the keys in the resident forward: 0 or 1 = one pass with a lazily moved reference point (measured against two
+// passes: 236 -> 207 us at 289 keys / head_dim 64 with swizzled images, 179 -> 173 us at 576 / 32, 37.0 -> 34.8 us at 196 / 32,
+// 37.3 -> 34.0 us at 99 / 64 with 4 waves once the kernel is bounded to 128 registers: unbounded the compiler spread that
+// instantiation over 168 and it lost), 2 = two passes, row maximum first
 static thread_local int g_fwd_one_pass = 0;
 extern "C" void mmae_attn_fwd_set_one_pass(int v) { g_fwd_one_pass = v; }
 template <int D, int NW>
 static int launch_fwd(const AttnArgs& a, hipStream_t s) {
     static bool reserved = false;
     const int nkp = pad32(a.kv_len);
-    if (g_fwd_one_pass == 1 || (g_fwd_one_pass == 0 && D == 32 && NW >= 8)) {
+    if (g_fwd_one_pass != 2) {
         static bool reserved1 = false;
-        return launch_with_lds(attn_fwd_kernel<D, NW, false, 1, true>, "attn_fwd", sizeof(bf16) * 2 * (size_t)nkp * (D + 8), a.B * a.H, NW * 64, s, a,
+        return launch_with_lds(attn_fwd_kernel<D, NW, false, 4, true>, "attn_fwd", sizeof(bf16) * 2 * (size_t)nkp * (D + 8), a.B * a.H, NW * 64, s, a,
                                nkp, reserved1);
     }
     return launch_with_lds(attn_fwd_kernel<D, NW, false, 1, false>, "attn_fwd", sizeof(bf16) * 2 * (size_t)nkp * (D + 8), a.B * a.H, NW * 64, s, a,
