@@ -387,6 +387,62 @@ def test_attention_forward_one_pass_follows_a_growing_maximum(ops, d, variant):
     assert rel_err(f(o), oref) < 6e-3 and rel_err(lse, lref) < 1e-4
 
 
+def test_attention_random_shapes_every_kernel_choice(ops):
+    """A seeded sweep of ragged problems (query and key counts 1..700 that fill no tile evenly, both head sizes) through every
+    forward form (by size, padded resident, streamed, swizzled resident; one and two passes) and every backward form that takes
+    the shape (by size, two kernels padded, one kernel, two kernels swizzled), against the fp32 reference."""
+    rng = np.random.default_rng(7)
+    L = ops._L()
+    for case in range(20):
+        d = int(rng.choice([32, 64]))
+        B, H = int(rng.integers(1, 3)), int(rng.integers(1, 4))
+        Nq, Nk = int(rng.integers(1, 700)), int(rng.integers(1, 700))
+        if case % 4 == 0:
+            Nk = Nq
+        scale = d ** -0.5
+        qbuf, kvbuf = _randn(B * Nq, H * d, seed=500 + case), _randn(B * Nk, 2 * H * d, seed=600 + case)
+        kv_, vv = kvbuf[:, :H * d], kvbuf[:, H * d:]
+        d_o = _randn(B * Nq, H * d, seed=700 + case)
+
+        def heads(t, n):
+            return t.float().reshape(B, n, H, d).permute(0, 2, 1, 3).clone().requires_grad_(True)
+        q4, k4, v4 = heads(qbuf, Nq), heads(kv_, Nk), heads(vv, Nk)
+        oref, lref = _attn_ref(q4, k4, v4, scale)
+        oref.backward(d_o.float().reshape(B, Nq, H, d).permute(0, 2, 1, 3))
+        back = lambda t4, n: t4.grad.permute(0, 2, 1, 3).reshape(B * n, H * d)
+        fits_fwd = Nk <= L.mmae_attn_max_len(d, 0)
+        fits_bwd = max(Nq, Nk) <= L.mmae_attn_max_len(d, 1)
+        o = lse = None
+        try:
+            for variant in (0, 1, 2, 3):
+                if variant == 1 and not fits_fwd:
+                    continue
+                for passes in (1, 2):
+                    L.mmae_attn_fwd_set_variant(variant)
+                    L.mmae_attn_fwd_set_one_pass(passes)
+                    o, lse = ops.attn_fwd(qbuf, kv_, vv, B, H, Nq, Nk, d, scale)
+                    tag = (case, B, H, Nq, Nk, d, variant, passes)
+                    assert rel_err(o.float().reshape(B, Nq, H, d).permute(0, 2, 1, 3), oref) < 6e-3, tag
+                    assert rel_err(lse, lref) < 1e-4, tag
+            L.mmae_attn_fwd_set_variant(0)
+            L.mmae_attn_fwd_set_one_pass(0)
+            o, lse = ops.attn_fwd(qbuf, kv_, vv, B, H, Nq, Nk, d, scale)
+            for variant in (0, 1, 2, 3):
+                if variant == 2 and not fits_bwd:
+                    continue   # the one-kernel form needs Q, dO, K, V of a head in LDS together; ops.attn_bwd chunks the others
+                L.mmae_attn_bwd_set_variant(variant)
+                dq = torch.zeros_like(qbuf); dkv = torch.zeros_like(kvbuf)
+                ops.attn_bwd(qbuf, kv_, vv, o, d_o, lse, dq, dkv[:, :H * d], dkv[:, H * d:], B, H, Nq, Nk, d, scale)
+                tag = (case, B, H, Nq, Nk, d, "bwd", variant)
+                assert rel_err(dq.float(), back(q4, Nq)) < BF16_TOL, tag
+                assert rel_err(dkv[:, :H * d].float(), back(k4, Nk)) < BF16_TOL, tag
+                assert rel_err(dkv[:, H * d:].float(), back(v4, Nk)) < BF16_TOL, tag
+        finally:
+            L.mmae_attn_fwd_set_variant(0)
+            L.mmae_attn_fwd_set_one_pass(0)
+            L.mmae_attn_bwd_set_variant(0)
+
+
 def test_attention_length_limit(ops):
     """The keys (forward, dQ) or queries (dK/dV) of one head live in LDS: the longest sequences that fit 160 KiB run in one
     call and agree with the reference, one 32-row tile more returns MMAE_ESHAPE before anything is launched; the limits are
